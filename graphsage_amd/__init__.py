@@ -1,0 +1,11 @@
+"""graphsage_amd: the GraphSAGE training hot path of celestice106/graphsage, written
+for MI355X (gfx950).  Host side = the reference's Python interfaces; device side =
+hand-written HIP kernels behind the C ABI in include/gsage.h (libgsage.so)."""
+from .graphsage import GraphSAGE, SAGEConv, create_model
+from .loss import SkipGramLoss, create_loss
+from .graph import GraphCSR, GraphCache, build_csr, default_cache
+from .train_step import TrainStep, FlatParams, shard_bounds
+
+__all__ = ["GraphSAGE", "SAGEConv", "create_model", "SkipGramLoss", "create_loss", "GraphCSR",
+           "GraphCache", "build_csr", "default_cache", "TrainStep", "FlatParams", "shard_bounds"]
+__version__ = "0.1.0"

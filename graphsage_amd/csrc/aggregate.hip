@@ -1,0 +1,271 @@
+// K2 / K7: segment gather over a CSR (SAGEConv mean aggregation and its transposed
+// backward) for gfx950.  HBM-bound: the only arithmetic is one add per gathered float.
+//
+//   out[i,:] = add_to[i,:] + s_i * sum_{p in row i} w_p * x[col[p],:]
+//
+// Layout: one wavefront per destination row.  A feature row of F floats is covered by
+// LPR = F/4 lanes with one 16-byte load each, so one wave-instruction fetches
+// G = 64/LPR whole neighbour rows (F=64: 4 rows of 256 B).  The row's neighbour ids
+// are fetched 64 at a time with one coalesced load and handed to the lanes with
+// ds_bpermute (the LDS crossbar; no LDS memory is touched).  Sums are kept in
+// registers and combined across the G lane groups by xor-shuffles in a fixed order,
+// so results are bitwise reproducible.  Rows longer than the hub threshold are left
+// to a second launch that gives a whole 1024-thread workgroup to each of them.
+#include "gsage_common.h"
+
+namespace {
+
+constexpr int AGG_BLOCK = 256;         // 4 waves, one row per wave per iteration
+constexpr int HUB_BLOCK = 1024;        // 16 waves per hub row
+
+template <int LPR>
+__device__ __forceinline__ float4 group_reduce(float4 a) {
+  // sum the G = 64/LPR lane groups; afterwards every lane holds the total of its column
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) {
+    a.x += __shfl_xor(a.x, o, 64);
+    a.y += __shfl_xor(a.y, o, 64);
+    a.z += __shfl_xor(a.z, o, 64);
+    a.w += __shfl_xor(a.w, o, 64);
+  }
+  return a;
+}
+
+// accumulate neighbours p in [p0, p1) of one row, visiting them in steps of
+// `stride_groups` neighbour slots (this wave owns every slot; hub waves share).
+template <int LPR, bool WEIGHTED>
+__device__ __forceinline__ float4 gather_range(const int *__restrict__ col,
+                                               const float *__restrict__ x,
+                                               const float *__restrict__ ew, int64_t F,
+                                               int p0, int p1) {
+  constexpr int G = 64 / LPR;
+  const int lane = gs_lane();
+  const int slot = lane / LPR, sub = lane % LPR;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int pc = p0; pc < p1; pc += 64) {
+    int pl = pc + lane;
+    int cv = pl < p1 ? col[pl] : 0;
+    int cnt = p1 - pc;
+    if (cnt > 64) cnt = 64;
+    int steps = (cnt + G - 1) / G;
+    int s = 0;
+    // 4 independent 16-byte loads in flight per lane
+    for (; s + 4 <= steps; s += 4) {
+      int j0 = (s + 0) * G + slot, j1 = (s + 1) * G + slot;
+      int j2 = (s + 2) * G + slot, j3 = (s + 3) * G + slot;
+      int c0 = __shfl(cv, j0, 64), c1 = __shfl(cv, j1, 64);
+      int c2 = __shfl(cv, j2, 64), c3 = __shfl(cv, j3, 64);
+      bool v0 = j0 < cnt, v1 = j1 < cnt, v2 = j2 < cnt, v3 = j3 < cnt;
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 r0 = v0 ? *(const float4 *)(x + (int64_t)c0 * F + sub * 4) : z;
+      float4 r1 = v1 ? *(const float4 *)(x + (int64_t)c1 * F + sub * 4) : z;
+      float4 r2 = v2 ? *(const float4 *)(x + (int64_t)c2 * F + sub * 4) : z;
+      float4 r3 = v3 ? *(const float4 *)(x + (int64_t)c3 * F + sub * 4) : z;
+      if (WEIGHTED) {
+        float w0 = v0 ? ew[c0] : 0.f, w1 = v1 ? ew[c1] : 0.f;
+        float w2 = v2 ? ew[c2] : 0.f, w3 = v3 ? ew[c3] : 0.f;
+        acc.x += r0.x * w0; acc.y += r0.y * w0; acc.z += r0.z * w0; acc.w += r0.w * w0;
+        acc.x += r1.x * w1; acc.y += r1.y * w1; acc.z += r1.z * w1; acc.w += r1.w * w1;
+        acc.x += r2.x * w2; acc.y += r2.y * w2; acc.z += r2.z * w2; acc.w += r2.w * w2;
+        acc.x += r3.x * w3; acc.y += r3.y * w3; acc.z += r3.z * w3; acc.w += r3.w * w3;
+      } else {
+        acc.x += r0.x; acc.y += r0.y; acc.z += r0.z; acc.w += r0.w;
+        acc.x += r1.x; acc.y += r1.y; acc.z += r1.z; acc.w += r1.w;
+        acc.x += r2.x; acc.y += r2.y; acc.z += r2.z; acc.w += r2.w;
+        acc.x += r3.x; acc.y += r3.y; acc.z += r3.z; acc.w += r3.w;
+      }
+    }
+    for (; s < steps; ++s) {
+      int j = s * G + slot;
+      int c = __shfl(cv, j, 64);
+      if (j < cnt) {
+        float4 r = *(const float4 *)(x + (int64_t)c * F + sub * 4);
+        float w = WEIGHTED ? ew[c] : 1.f;
+        acc.x += r.x * w; acc.y += r.y * w; acc.z += r.z * w; acc.w += r.w * w;
+      }
+    }
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------- vector path, F = 4*LPR
+template <int LPR, bool WEIGHTED>
+__global__ void __launch_bounds__(AGG_BLOCK)
+seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
+                 const float *__restrict__ row_scale, const float *__restrict__ ew,
+                 const float *__restrict__ x, const float *add_to, int64_t N, int64_t F,
+                 float *out, int long_t) {
+  const int lane = gs_lane();
+  const int slot = lane / LPR, sub = lane % LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * (AGG_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (AGG_BLOCK / 64);
+  for (int64_t row = wave0; row < N; row += nwaves) {
+    int p0 = rowptr[row], p1 = rowptr[row + 1];
+    if (long_t > 0 && p1 - p0 > long_t) continue;  // hub pass owns this row
+    float4 acc = gather_range<LPR, WEIGHTED>(col, x, ew, F, p0, p1);
+    acc = group_reduce<LPR>(acc);
+    if (slot == 0) {
+      float s = row_scale ? row_scale[row] : 1.f;
+      float4 o = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
+      int64_t off = row * F + sub * 4;
+      if (add_to) {
+        float4 a = *(const float4 *)(add_to + off);
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      }
+      *(float4 *)(out + off) = o;
+    }
+  }
+}
+
+// hub rows: one 16-wave workgroup per row; waves take interleaved 64-neighbour chunks,
+// partial sums are combined through LDS in wave order (fixed => reproducible).
+template <int LPR, bool WEIGHTED>
+__global__ void __launch_bounds__(HUB_BLOCK)
+seg_gather_hub_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
+                     const float *__restrict__ row_scale, const float *__restrict__ ew,
+                     const float *__restrict__ x, const float *add_to, int64_t F, float *out,
+                     const int *__restrict__ long_rows, const int *__restrict__ n_long,
+                     int64_t long_cap) {
+  __shared__ float4 part[HUB_BLOCK / 64][LPR];
+  const int lane = gs_lane(), wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR;
+  int nl = *n_long;
+  if (nl > long_cap) nl = (int)long_cap;
+  for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+    int64_t row = long_rows[li];
+    int p0 = rowptr[row], p1 = rowptr[row + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pc = p0 + wave * 64; pc < p1; pc += (HUB_BLOCK / 64) * 64) {
+      int pe = pc + 64 < p1 ? pc + 64 : p1;
+      float4 r = gather_range<LPR, WEIGHTED>(col, x, ew, F, pc, pe);
+      acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+    }
+    acc = group_reduce<LPR>(acc);
+    if (slot == 0) part[wave][sub] = acc;
+    __syncthreads();
+    if (wave == 0 && slot == 0) {
+      float4 t = part[0][sub];
+      for (int w = 1; w < HUB_BLOCK / 64; ++w) {
+        float4 q = part[w][sub];
+        t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+      }
+      float s = row_scale ? row_scale[row] : 1.f;
+      float4 o = make_float4(t.x * s, t.y * s, t.z * s, t.w * s);
+      int64_t off = row * F + sub * 4;
+      if (add_to) {
+        float4 a = *(const float4 *)(add_to + off);
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      }
+      *(float4 *)(out + off) = o;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------- scalar path, any F (e.g. F = 7)
+// P = lanes per neighbour slot (power of two >= min(F,64)); each lane owns feature
+// columns sub, sub+P, ... of its slot's neighbour.  Up to 4 columns per lane are kept
+// in registers per sweep (F <= 4*P per sweep; larger F sweeps the row again).
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(AGG_BLOCK)
+seg_gather_scalar_k(const int *__restrict__ rowptr, const int *__restrict__ col,
+                    const float *__restrict__ row_scale, const float *__restrict__ ew,
+                    const float *__restrict__ x, const float *add_to, int64_t N, int64_t F,
+                    float *out, int P) {
+  const int lane = gs_lane();
+  const int G = 64 / P;
+  const int slot = lane / P, sub = lane % P;
+  const int64_t wave0 = (int64_t)blockIdx.x * (AGG_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (AGG_BLOCK / 64);
+  for (int64_t row = wave0; row < N; row += nwaves) {
+    int p0 = rowptr[row], p1 = rowptr[row + 1];
+    float s = row_scale ? row_scale[row] : 1.f;
+    for (int64_t f0 = 0; f0 < F; f0 += P) {
+      int64_t f = f0 + sub;
+      float acc = 0.f;
+      for (int pc = p0; pc < p1; pc += 64) {
+        int pl = pc + lane;
+        int cv = pl < p1 ? col[pl] : 0;
+        int cnt = p1 - pc;
+        if (cnt > 64) cnt = 64;
+        int steps = (cnt + G - 1) / G;
+        for (int st = 0; st < steps; ++st) {
+          int j = st * G + slot;
+          int c = __shfl(cv, j, 64);
+          if (j < cnt && f < F) {
+            float w = WEIGHTED ? ew[c] : 1.f;
+            acc += x[(int64_t)c * F + f] * w;
+          }
+        }
+      }
+      for (int o = P; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+      if (slot == 0 && f < F) {
+        float o = acc * s;
+        if (add_to) o += add_to[row * F + f];
+        out[row * F + f] = o;
+      }
+    }
+  }
+}
+
+template <int LPR>
+int launch_vec(const int *rowptr, const int *col, const float *row_scale, const float *ew,
+               const float *x, const float *add_to, int64_t N, int64_t F, float *out,
+               const int *long_rows, const int *n_long, hipStream_t st) {
+  int grid = gs_grid(N, AGG_BLOCK / 64, 256 * 64);
+  int long_t = (long_rows && n_long) ? gsage_long_row_threshold() : 0;
+  int64_t long_cap = 0x7fffffff;
+  if (ew)
+    hipLaunchKernelGGL((seg_gather_vec_k<LPR, true>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
+                       col, row_scale, ew, x, add_to, N, F, out, long_t);
+  else
+    hipLaunchKernelGGL((seg_gather_vec_k<LPR, false>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
+                       col, row_scale, ew, x, add_to, N, F, out, long_t);
+  GSAGE_CHECK_LAUNCH();
+  if (long_t > 0) {
+    if (ew)
+      hipLaunchKernelGGL((seg_gather_hub_vec_k<LPR, true>), dim3(256), dim3(HUB_BLOCK), 0, st,
+                         rowptr, col, row_scale, ew, x, add_to, F, out, long_rows, n_long,
+                         long_cap);
+    else
+      hipLaunchKernelGGL((seg_gather_hub_vec_k<LPR, false>), dim3(256), dim3(HUB_BLOCK), 0, st,
+                         rowptr, col, row_scale, ew, x, add_to, F, out, long_rows, n_long,
+                         long_cap);
+    GSAGE_CHECK_LAUNCH();
+  }
+  return GSAGE_OK;
+}
+
+}  // namespace
+
+extern "C" int gsage_segment_gather(const int32_t *rowptr, const int32_t *col,
+                                    const float *row_scale, const float *edge_weight,
+                                    const float *x, const float *add_to, int64_t N, int64_t F,
+                                    float *out, const int32_t *long_rows, const int32_t *n_long,
+                                    gsage_stream_t stream) {
+  if (N < 0 || F <= 0 || !rowptr || !x || !out) return GSAGE_ERR_INVALID_ARG;
+  if (N == 0) return GSAGE_OK;
+  hipStream_t st = gs_stream(stream);
+  bool aligned = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)add_to) & 15) == 0;
+  if (aligned) {
+    switch (F) {
+      case 16:  return launch_vec<4>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
+      case 32:  return launch_vec<8>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
+      case 64:  return launch_vec<16>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
+      case 128: return launch_vec<32>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
+      case 256: return launch_vec<64>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
+      default: break;
+    }
+  }
+  int P = 1;
+  while (P < F && P < 64) P <<= 1;
+  int grid = gs_grid(N, AGG_BLOCK / 64, 256 * 64);
+  if (edge_weight)
+    hipLaunchKernelGGL((seg_gather_scalar_k<true>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr, col,
+                       row_scale, edge_weight, x, add_to, N, F, out, P);
+  else
+    hipLaunchKernelGGL((seg_gather_scalar_k<false>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
+                       col, row_scale, edge_weight, x, add_to, N, F, out, P);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}

@@ -1,0 +1,375 @@
+// K1: CSR build for gfx950.  int64 [2,E] edge list -> int32 CSR in both orientations
+// with stable (ascending edge id) order inside each row, plus inv_deg and hub-row lists.
+//
+// Method: validate+narrow to int32 -> degree histogram (integer atomics, exact) ->
+// exclusive scan -> stable LSD radix sort of (key,value) pairs by key.  Each radix
+// pass is histogram / scan / scatter; the scatter ranks items with wave ballots, so
+// the order inside a bucket is the input order (tile, wave, round, lane) = stable.
+// Everything is integer work: results are bit-exact and run-to-run identical.
+#include "gsage_common.h"
+
+namespace {
+
+constexpr int SCAN_T = 256;
+constexpr int SCAN_IPT = 8;
+constexpr int SCAN_CH = SCAN_T * SCAN_IPT;  // 2048 ints per block
+
+constexpr int RS_T = 256;                   // radix sort block
+constexpr int RS_ROUNDS = 16;               // items per lane
+constexpr int RS_TILE = RS_T * RS_ROUNDS;   // 4096 items per block
+constexpr int RS_WAVE_ITEMS = 64 * RS_ROUNDS;
+
+constexpr int LONG_ROW_T = 2048;            // rows longer than this take the hub pass
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  const int lane = gs_lane();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------ narrow + validate
+// src32/dst32 <- edge_index rows; an edge with any index outside [0,N) gets key N on
+// both sides (a sentinel row that sorts last and is never read) and raises the flag.
+__global__ void narrow_validate_k(const int64_t *__restrict__ ei, int64_t E, int64_t N,
+                                  int *__restrict__ src32, int *__restrict__ dst32,
+                                  int *__restrict__ status) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad_any = false;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
+    int64_t s = ei[e], d = ei[E + e];
+    bool bad = (s < 0) | (s >= N) | (d < 0) | (d >= N);
+    src32[e] = bad ? (int)N : (int)s;
+    dst32[e] = bad ? (int)N : (int)d;
+    bad_any |= bad;
+  }
+  if (bad_any) atomicOr(status, GSAGE_FLAG_INDEX_OUT_OF_RANGE);
+}
+
+__global__ void degree_k(const int *__restrict__ key, int64_t E, int *__restrict__ deg) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride)
+    atomicAdd(&deg[key[e]], 1);
+}
+
+__global__ void inv_deg_k(const int *__restrict__ deg, int64_t N, float *__restrict__ inv_deg) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    int d = deg[i];
+    inv_deg[i] = 1.0f / (float)(d > 1 ? d : 1);
+  }
+}
+
+__global__ void long_rows_k(const int *__restrict__ rowptr, int64_t N, int *__restrict__ list,
+                            int64_t cap, int *__restrict__ count) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+    if (rowptr[i + 1] - rowptr[i] > LONG_ROW_T) {
+      int pos = atomicAdd(count, 1);
+      if (pos < cap) list[pos] = (int)i;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ scan
+__global__ void scan_reduce_k(const int *__restrict__ in, int64_t n, int *__restrict__ bsum) {
+  __shared__ int sh[SCAN_T / 64];
+  int64_t base = (int64_t)blockIdx.x * SCAN_CH;
+  int s = 0;
+  for (int i = threadIdx.x; i < SCAN_CH; i += SCAN_T) {
+    int64_t g = base + i;
+    if (g < n) s += in[g];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (gs_lane() == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < SCAN_T / 64; ++w) t += sh[w];
+    bsum[blockIdx.x] = t;
+  }
+}
+
+// one block of 1024 threads: exclusive scan of bsum[nb] in place
+__global__ void scan_spine_k(int *__restrict__ bsum, int64_t nb) {
+  __shared__ int wsum[16];
+  const int lane = gs_lane(), wave = threadIdx.x >> 6;
+  int carry = 0;
+  for (int64_t base = 0; base < nb; base += 1024) {
+    int64_t i = base + threadIdx.x;
+    int v = i < nb ? bsum[i] : 0;
+    int inc = wave_incl_scan(v);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      int x = wsum[w];
+      if (w < wave) woff += x;
+      total += x;
+    }
+    if (i < nb) bsum[i] = carry + woff + inc - v;
+    carry += total;
+    __syncthreads();
+  }
+}
+
+__global__ void scan_apply_k(const int *__restrict__ in, int64_t n,
+                             const int *__restrict__ bsum_excl, int *__restrict__ out) {
+  __shared__ int ch[SCAN_CH];
+  __shared__ int wsum[SCAN_T / 64];
+  const int t = threadIdx.x, lane = gs_lane(), wave = t >> 6;
+  int64_t base = (int64_t)blockIdx.x * SCAN_CH;
+  for (int i = t; i < SCAN_CH; i += SCAN_T) {
+    int64_t g = base + i;
+    ch[i] = g < n ? in[g] : 0;
+  }
+  __syncthreads();
+  int loc[SCAN_IPT];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_IPT; ++j) {
+    loc[j] = ch[t * SCAN_IPT + j];
+    s += loc[j];
+  }
+  int inc = wave_incl_scan(s);
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wsum[w];
+  int run = bsum_excl[blockIdx.x] + woff + inc - s;
+#pragma unroll
+  for (int j = 0; j < SCAN_IPT; ++j) {
+    ch[t * SCAN_IPT + j] = run;
+    run += loc[j];
+  }
+  __syncthreads();
+  for (int i = t; i < SCAN_CH; i += SCAN_T) {
+    int64_t g = base + i;
+    if (g < n) out[g] = ch[i];
+  }
+}
+
+// exclusive scan of in[0..n) into out[0..n) (in may equal out); bsum: ceil(n/SCAN_CH) ints
+int exclusive_scan(const int *in, int64_t n, int *out, int *bsum, hipStream_t st) {
+  if (n <= 0) return GSAGE_OK;
+  int64_t nb = (n + SCAN_CH - 1) / SCAN_CH;
+  hipLaunchKernelGGL(scan_reduce_k, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, bsum);
+  hipLaunchKernelGGL(scan_spine_k, dim3(1), dim3(1024), 0, st, bsum, nb);
+  hipLaunchKernelGGL(scan_apply_k, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, bsum, out);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}
+
+// ------------------------------------------------------------------------ radix pass
+__global__ void radix_hist_k(const int *__restrict__ keys, int64_t n, int shift, int mask,
+                             int *__restrict__ counts, int64_t ntiles) {
+  __shared__ int h[256];
+  const int t = threadIdx.x;
+  h[t] = 0;
+  __syncthreads();
+  int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    int64_t idx = base + (int64_t)r * RS_T + t;
+    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1);
+  }
+  __syncthreads();
+  if (t <= mask) counts[(int64_t)t * ntiles + blockIdx.x] = h[t];
+}
+
+__global__ void __launch_bounds__(RS_T)
+radix_scatter_k(const int *__restrict__ kin, const int *__restrict__ vin, int64_t n,
+                int shift, int mask, int width, const int *__restrict__ offs,
+                int64_t ntiles, int *__restrict__ kout, int *__restrict__ vout) {
+  __shared__ int whist[RS_T / 64][256];
+  const int t = threadIdx.x, lane = gs_lane(), w = t >> 6;
+  for (int i = t; i < (RS_T / 64) * 256; i += RS_T) (&whist[0][0])[i] = 0;
+  __syncthreads();
+
+  const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * RS_WAVE_ITEMS;
+  int k[RS_ROUNDS], v[RS_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    int64_t idx = wbase + r * 64 + lane;
+    bool valid = idx < n;
+    k[r] = valid ? kin[idx] : 0;
+    v[r] = valid ? vin[idx] : 0;
+  }
+  // phase 1: per-wave digit histogram
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    int64_t idx = wbase + r * 64 + lane;
+    if (idx < n) atomicAdd(&whist[w][(k[r] >> shift) & mask], 1);
+  }
+  __syncthreads();
+  // per-digit bases: global offset of (digit, tile) then the waves in order
+  if (t <= mask) {
+    int b = offs[(int64_t)t * ntiles + blockIdx.x];
+#pragma unroll
+    for (int ww = 0; ww < RS_T / 64; ++ww) {
+      int c = whist[ww][t];
+      whist[ww][t] = b;
+      b += c;
+    }
+  }
+  __syncthreads();
+  // phase 2: stable ranks inside the wave, round by round
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    int64_t idx = wbase + r * 64 + lane;
+    bool valid = idx < n;
+    int d = (k[r] >> shift) & mask;
+    unsigned long long m = __ballot(valid);
+    for (int b = 0; b < width; ++b) {
+      bool bit = (d >> b) & 1;
+      unsigned long long bb = __ballot(bit);
+      m &= bit ? bb : ~bb;
+    }
+    int rank = __popcll(m & ((1ull << lane) - 1ull));
+    int leader = __ffsll((long long)m) - 1;
+    int basev = 0;
+    if (valid && lane == leader) {
+      basev = whist[w][d];
+      whist[w][d] = basev + __popcll(m);
+    }
+    basev = __shfl(basev, leader & 63, 64);
+    if (valid) {
+      int pos = basev + rank;
+      if (kout) kout[pos] = k[r];
+      vout[pos] = v[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+struct SortWs {
+  int *kA, *vA, *kB, *vB, *counts, *bsum;
+};
+
+// stable sort of (key,val) by key in [0, 2^bits); the sorted values land in vout_final.
+int radix_sort_vals(const int *keys, const int *vals, int64_t n, int bits, int *vout_final,
+                    const SortWs &ws, hipStream_t st) {
+  if (n <= 0) return GSAGE_OK;
+  if (bits < 1) bits = 1;
+  int passes = (bits + 7) / 8;
+  int width = (bits + passes - 1) / passes;
+  int64_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+  const int *kin = keys, *vin = vals;
+  for (int p = 0; p < passes; ++p) {
+    int shift = p * width;
+    int mask = (1 << width) - 1;
+    bool last = (p == passes - 1);
+    int *kout = last ? nullptr : ((p & 1) ? ws.kB : ws.kA);
+    int *vout = last ? vout_final : ((p & 1) ? ws.vB : ws.vA);
+    hipLaunchKernelGGL(radix_hist_k, dim3((unsigned)ntiles), dim3(RS_T), 0, st, kin, n, shift,
+                       mask, ws.counts, ntiles);
+    int64_t ncounts = (int64_t)(mask + 1) * ntiles;
+    int rc = exclusive_scan(ws.counts, ncounts, ws.counts, ws.bsum, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(radix_scatter_k, dim3((unsigned)ntiles), dim3(RS_T), 0, st, kin, vin, n,
+                       shift, mask, width, ws.counts, ntiles, kout, vout);
+    GSAGE_CHECK_LAUNCH();
+    kin = kout;
+    vin = vout;
+  }
+  return GSAGE_OK;
+}
+
+struct CsrWsLayout {
+  size_t total;
+  size_t o_src, o_dst, o_kA, o_vA, o_kB, o_vB, o_counts, o_bsum, o_deg;
+};
+
+CsrWsLayout csr_layout(int64_t E, int64_t N) {
+  CsrWsLayout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += gs_align_up(bytes ? bytes : 4, 256);
+    return o;
+  };
+  size_t e4 = (size_t)(E > 0 ? E : 1) * 4;
+  int64_t ntiles = (E + RS_TILE - 1) / RS_TILE;
+  if (ntiles < 1) ntiles = 1;
+  int64_t ncounts = 256 * ntiles;
+  int64_t scan_n = ncounts > (N + 2) ? ncounts : (N + 2);
+  L.o_src = take(e4);
+  L.o_dst = take(e4);
+  L.o_kA = take(e4);
+  L.o_vA = take(e4);
+  L.o_kB = take(e4);
+  L.o_vB = take(e4);
+  L.o_counts = take((size_t)ncounts * 4);
+  L.o_bsum = take((size_t)((scan_n + SCAN_CH - 1) / SCAN_CH + 1) * 4);
+  L.o_deg = take((size_t)(N + 2) * 4);
+  L.total = off;
+  return L;
+}
+
+}  // namespace
+
+extern "C" int gsage_long_row_threshold(void) { return LONG_ROW_T; }
+
+extern "C" size_t gsage_csr_workspace_bytes(int64_t E, int64_t N) {
+  if (E < 0 || N < 0) return 0;
+  return csr_layout(E, N).total;
+}
+
+extern "C" int gsage_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr,
+                               int32_t *col, int32_t *rowptr_t, int32_t *col_t, float *inv_deg,
+                               int32_t *long_rows, int32_t *long_rows_t, int64_t long_cap,
+                               int32_t *n_long, int32_t *status, void *ws, size_t ws_bytes,
+                               gsage_stream_t stream) {
+  if (E < 0 || N < 0 || !rowptr || !rowptr_t || !inv_deg || !status || !ws)
+    return GSAGE_ERR_INVALID_ARG;
+  if (E > 0 && (!edge_index || !col || !col_t)) return GSAGE_ERR_INVALID_ARG;
+  if (E >= (1ll << 31) - 1 || N >= (1ll << 31) - 2) return GSAGE_ERR_UNSUPPORTED;
+  CsrWsLayout L = csr_layout(E, N);
+  if (ws_bytes < L.total) return GSAGE_ERR_WORKSPACE;
+  hipStream_t st = gs_stream(stream);
+  char *b = (char *)ws;
+  int *src32 = (int *)(b + L.o_src), *dst32 = (int *)(b + L.o_dst);
+  SortWs sw{(int *)(b + L.o_kA), (int *)(b + L.o_vA), (int *)(b + L.o_kB),
+            (int *)(b + L.o_vB), (int *)(b + L.o_counts), (int *)(b + L.o_bsum)};
+  int *deg = (int *)(b + L.o_deg);
+
+  if (E > 0) {
+    hipLaunchKernelGGL(narrow_validate_k, dim3(gs_grid(E, 256)), dim3(256), 0, st, edge_index, E,
+                       N, src32, dst32, status);
+    GSAGE_CHECK_LAUNCH();
+  }
+  int bits = 0;
+  while ((1ll << bits) <= N) ++bits;  // bits needed to hold the sentinel key N
+
+  if (n_long && hipMemsetAsync(n_long, 0, 2 * sizeof(int32_t), st) != hipSuccess)
+    return GSAGE_ERR_LAUNCH;
+
+  for (int orient = 0; orient < 2; ++orient) {
+    const int *key = orient == 0 ? dst32 : src32;
+    const int *val = orient == 0 ? src32 : dst32;
+    int32_t *rp = orient == 0 ? rowptr : rowptr_t;
+    int32_t *cl = orient == 0 ? col : col_t;
+    if (hipMemsetAsync(deg, 0, (size_t)(N + 2) * 4, st) != hipSuccess) return GSAGE_ERR_LAUNCH;
+    if (E > 0)
+      hipLaunchKernelGGL(degree_k, dim3(gs_grid(E, 256)), dim3(256), 0, st, key, E, deg);
+    if (orient == 0 && N > 0)
+      hipLaunchKernelGGL(inv_deg_k, dim3(gs_grid(N, 256)), dim3(256), 0, st, deg, N, inv_deg);
+    GSAGE_CHECK_LAUNCH();
+    // rowptr[0..N] = exclusive scan of deg[0..N] (deg[N] = dropped edges)
+    int rc = exclusive_scan(deg, N + 1, rp, sw.bsum, st);
+    if (rc) return rc;
+    rc = radix_sort_vals(key, val, E, bits, cl, sw, st);
+    if (rc) return rc;
+    int32_t *lr = orient == 0 ? long_rows : long_rows_t;
+    if (lr && n_long && N > 0 && long_cap > 0) {
+      hipLaunchKernelGGL(long_rows_k, dim3(gs_grid(N, 256)), dim3(256), 0, st, rp, N, lr, long_cap,
+                         n_long + orient);
+      GSAGE_CHECK_LAUNCH();
+    }
+  }
+  return GSAGE_OK;
+}

@@ -1,0 +1,46 @@
+// Shared helpers for the gfx950 kernels of libgsage.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "gsage.h"
+
+#define GSAGE_WAVE 64
+
+#define GSAGE_CHECK_LAUNCH()                                   \
+  do {                                                         \
+    if (hipGetLastError() != hipSuccess) return GSAGE_ERR_LAUNCH; \
+  } while (0)
+
+static inline hipStream_t gs_stream(gsage_stream_t s) { return (hipStream_t)s; }
+
+static inline size_t gs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Carve a workspace: returns pointer at current offset, advances by bytes (256-B aligned).
+struct GsCarver {
+  char *base;
+  size_t off;
+  explicit GsCarver(void *p) : base((char *)p), off(0) {}
+  template <typename T> T *take(size_t count) {
+    T *r = (T *)(base + off);
+    off += gs_align_up(count * sizeof(T), 256);
+    return r;
+  }
+};
+
+__device__ __forceinline__ int gs_lane() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float gs_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Grid size for a grid-stride kernel: enough blocks to fill 256 CUs, capped.
+static inline int gs_grid(int64_t work_items, int per_block, int cap = 256 * 8) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}

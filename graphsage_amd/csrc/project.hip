@@ -1,0 +1,710 @@
+// K3: SAGEConv projections for gfx950, forward and backward.
+//
+//   fwd : out = epi( [agg | x] . [W_l | W_r]^T + b_l )      epi in {none, relu, relu+dropout, l2norm}
+//   bwd : dpre = epi'(grad_out);  [grad_agg | grad_x] = dpre . [W_l | W_r];
+//         [grad_W_l | grad_W_r] = dpre^T . [agg | x];  grad_b = colsum(dpre)
+//
+// Two code paths, chosen by shape only (there is no CPU or library fallback):
+//   * MFMA path (Fi, Fo in {64,128,256}): fp32-input v_mfma_f32_32x32x2_f32, 64-row
+//     tiles staged through LDS in 32-deep K chunks with register prefetch; the result
+//     is a k-ordered fp32 fma chain, i.e. exact fp32 like the reference's F.linear.
+//   * VALU path (any shape; the 7-wide first layer uses its small-K specialisation
+//     with the weights held in registers).
+// Weight gradients are accumulated per workgroup into partial slabs and summed in slab
+// order by a second kernel: no atomics, bitwise reproducible.
+#include "gsage_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr float L2_EPS = 1e-12f;
+
+// ------------------------------------------------------------------ dropout hash RNG
+// keep(seed, idx) with idx = row*Fo + col; mirrored in graphsage_amd/rng.py for tests.
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, float p) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0,1)
+  return u >= p;
+}
+
+struct EpiArgs {
+  int mode;
+  const float *bias;
+  const uint8_t *keep_mask;
+  uint64_t seed;
+  float p;
+  float inv_keep;
+  float *rnorm;
+  const float *row_scale;  // dX: scale of destination 1
+};
+
+// ------------------------------------------------------------------------ weight packs
+// fwd pack: Bp[n][k] (n < Fo, k < 2Fi) = k < Fi ? W_l[n][k] : W_r[n][k-Fi]
+__global__ void pack_fwd_k(const float *__restrict__ wl, const float *__restrict__ wr, int Fi,
+                           int Fo, float *__restrict__ bp) {
+  int total = Fo * 2 * Fi;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int n = e / (2 * Fi), k = e % (2 * Fi);
+    bp[e] = k < Fi ? wl[n * Fi + k] : wr[n * Fi + k - Fi];
+  }
+}
+// dX pack: Bp[n][k] (n < 2Fi, k < Fo) = n < Fi ? W_l[k][n] : W_r[k][n-Fi]
+__global__ void pack_dx_k(const float *__restrict__ wl, const float *__restrict__ wr, int Fi,
+                          int Fo, float *__restrict__ bp) {
+  int total = 2 * Fi * Fo;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int n = e / Fo, k = e % Fo;
+    bp[e] = n < Fi ? wl[k * Fi + n] : wr[k * Fi + n - Fi];
+  }
+}
+// VALU pack: Wt[k][j] (k < 2Fi, j < Fo) = k < Fi ? W_l[j][k] : W_r[j][k-Fi]
+__global__ void pack_t_k(const float *__restrict__ wl, const float *__restrict__ wr, int Fi,
+                         int Fo, float *__restrict__ wt) {
+  int total = 2 * Fi * Fo;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int k = e / Fo, j = e % Fo;
+    wt[e] = k < Fi ? wl[j * Fi + k] : wr[j * Fi + k - Fi];
+  }
+}
+
+// =============================================================================== MFMA
+struct GemmArgs {
+  const float *A1, *A2;  // A = [A1 | A2], A1 is [M,K1], A2 is [M,K-K1] (A2 unused if K1 == K)
+  const float *Bp;       // [Ncols, K] row-major
+  float *C1, *C2;        // blockIdx.y*BN <  N1 -> C1 [M,N1];  else C2 [M,Ncols-N1]
+  int64_t M;
+  int K1, K, N1, Ncols;
+  EpiArgs epi;
+};
+
+constexpr int G_BK = 32;
+constexpr int G_PITCH = G_BK + 4;
+
+constexpr int MODE_DX = 100;  // epilogue of the dX GEMM (scale dest 1 rows, no bias)
+
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256) gemm_rows_k(GemmArgs a) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int NA = BM / 32, NB = BN / 32;  // float4 per thread per chunk
+  constexpr int CP = BN + 4;
+  extern __shared__ __align__(16) float smem[];
+  float *As = smem;
+  float *Bs = smem + BM * G_PITCH;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w / WN, wn = w % WN;
+  const int64_t row0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int K = a.K, K1 = a.K1, K2 = a.K - a.K1;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[NA], rb[NB];
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int f = t + i * 256;
+      int r = f >> 3, c4 = f & 7;
+      int64_t grow = row0 + r;
+      int k = kc + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (grow < a.M) {
+        const float *src = (k < K1) ? a.A1 + grow * K1 + k : a.A2 + grow * K2 + (k - K1);
+        v = *(const float4 *)src;
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int f = t + i * 256;
+      int n = f >> 3, c4 = f & 7;
+      rb[i] = *(const float4 *)(a.Bp + (int64_t)(n0 + n) * K + kc + c4 * 4);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int f = t + i * 256;
+      *(float4 *)(As + (f >> 3) * G_PITCH + (f & 7) * 4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int f = t + i * 256;
+      *(float4 *)(Bs + (f >> 3) * G_PITCH + (f & 7) * 4) = rb[i];
+    }
+  };
+
+  gload(0);
+  for (int kc = 0; kc < K; kc += G_BK) {
+    sstore();
+    __syncthreads();
+    if (kc + G_BK < K) gload(kc + G_BK);
+#pragma unroll
+    for (int g = 0; g < G_BK / 8; ++g) {
+      float4 af[TM], bf[TN];
+      const int koff = g * 8 + (lane >> 5) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *(const float4 *)(As + ((wm * TM + i) * 32 + (lane & 31)) * G_PITCH + koff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *(const float4 *)(Bs + ((wn * TN + j) * 32 + (lane & 31)) * G_PITCH + koff);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float av = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+            float bv = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+    }
+    __syncthreads();
+  }
+
+  // accumulators -> LDS tile Cs[BM][CP]
+  float *Cs = smem;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int col = (wn * TN + j) * 32 + (lane & 31);
+        Cs[row * CP + col] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  // row-wise epilogue: BN/4 lanes per row, float4 each
+  constexpr int LPRo = BN / 4;
+  constexpr int RP = 256 / LPRo;
+  const int rsub = t / LPRo, c = t % LPRo;
+  const EpiArgs &e = a.epi;
+  const bool second = n0 >= a.N1;
+  float *C = second ? a.C2 : a.C1;
+  const int ldc = second ? (a.Ncols - a.N1) : a.N1;
+  const int cbase = second ? (n0 - a.N1) : n0;
+  for (int r = rsub; r < BM; r += RP) {
+    int64_t grow = row0 + r;
+    bool live = grow < a.M;
+    float4 v = *(const float4 *)(Cs + r * CP + c * 4);
+    int col = cbase + c * 4;
+    if (e.mode == MODE_DX) {
+      if (!second && e.row_scale && live) {
+        float s = e.row_scale[grow];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+      }
+    } else {
+      float4 b = *(const float4 *)(e.bias + col);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (e.mode == GSAGE_EPI_RELU_DROPOUT && live) {
+        uint64_t idx = (uint64_t)grow * (uint64_t)ldc + (uint64_t)col;
+        bool k0, k1, k2, k3;
+        if (e.keep_mask) {
+          uchar4 m = *(const uchar4 *)(e.keep_mask + idx);
+          k0 = m.x; k1 = m.y; k2 = m.z; k3 = m.w;
+        } else {
+          k0 = dropout_keep(e.seed, idx + 0, e.p); k1 = dropout_keep(e.seed, idx + 1, e.p);
+          k2 = dropout_keep(e.seed, idx + 2, e.p); k3 = dropout_keep(e.seed, idx + 3, e.p);
+        }
+        v.x = k0 ? v.x * e.inv_keep : 0.f; v.y = k1 ? v.y * e.inv_keep : 0.f;
+        v.z = k2 ? v.z * e.inv_keep : 0.f; v.w = k3 ? v.w * e.inv_keep : 0.f;
+      }
+      if (e.mode == GSAGE_EPI_L2NORM) {
+        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+        for (int o = 1; o < LPRo; o <<= 1) ss += __shfl_xor(ss, o, 64);
+        float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
+        v.x *= rn; v.y *= rn; v.z *= rn; v.w *= rn;
+        if (live && c == 0 && e.rnorm) e.rnorm[grow] = rn;
+      }
+    }
+    if (live) *(float4 *)(C + grow * ldc + col) = v;
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_gemm(const GemmArgs &a, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int stage = (BM + BN) * G_PITCH, ctile = BM * (BN + 4);
+  constexpr size_t lds = sizeof(float) * (stage > ctile ? stage : ctile);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)gemm_rows_k<WM, WN, TM, TN>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GSAGE_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Ncols / BN));
+  hipLaunchKernelGGL((gemm_rows_k<WM, WN, TM, TN>), grid, dim3(256), lds, st, a);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}
+
+int launch_gemm_bn(int BN, const GemmArgs &a, hipStream_t st) {
+  switch (BN) {
+    case 64:  return launch_gemm<2, 2, 1, 1>(a, st);
+    case 128: return launch_gemm<1, 4, 2, 1>(a, st);
+    case 256: return launch_gemm<1, 4, 2, 2>(a, st);
+    default:  return GSAGE_ERR_UNSUPPORTED;
+  }
+}
+
+// ---- dW = dpre^T . [agg | x] with the row index as the MFMA K dimension.
+// Output tile 64 (Fo) x 128 (2Fi cols) per workgroup; grid.x = row chunks (slabs),
+// grid.y = output tiles.  slab layout: [Fo][2Fi] then [Fo] bias sums.
+constexpr int DW_RK = 32;  // rows per chunk
+__global__ void __launch_bounds__(256)
+dw_mfma_k(const float *__restrict__ dpre, const float *__restrict__ agg,
+          const float *__restrict__ x, int64_t M, int Fi, int Fo, int64_t rows_per_block,
+          float *__restrict__ slabs) {
+  __shared__ __align__(16) float Ds[DW_RK][64];
+  __shared__ __align__(16) float Ac[DW_RK][128];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int K2 = 2 * Fi;
+  const int ntn = K2 / 128;
+  const int mt = blockIdx.y / ntn, nt = blockIdx.y % ntn;
+  const int m0 = mt * 64, c0 = nt * 128;
+  int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > M) r_end = M;
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  float bsum = 0.f;
+
+  float4 rd[2], rc[4];
+  auto gload = [&](int64_t rb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int f = t + i * 256;           // 512 float4: row = f>>4, c4 = f&15
+      int64_t row = rb + (f >> 4);
+      rd[i] = row < r_end ? *(const float4 *)(dpre + row * Fo + m0 + (f & 15) * 4)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int f = t + i * 256;           // 1024 float4: row = f>>5, c4 = f&31
+      int64_t row = rb + (f >> 5);
+      int n = c0 + (f & 31) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < r_end) v = n < Fi ? *(const float4 *)(agg + row * Fi + n)
+                                  : *(const float4 *)(x + row * Fi + (n - Fi));
+      rc[i] = v;
+    }
+  };
+  if (r_begin < r_end) gload(r_begin);
+  for (int64_t rb = r_begin; rb < r_end; rb += DW_RK) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int f = t + i * 256;
+      *(float4 *)(&Ds[f >> 4][(f & 15) * 4]) = rd[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int f = t + i * 256;
+      *(float4 *)(&Ac[f >> 5][(f & 31) * 4]) = rc[i];
+    }
+    __syncthreads();
+    if (rb + DW_RK < r_end) gload(rb + DW_RK);
+#pragma unroll
+    for (int kk = 0; kk < DW_RK / 2; ++kk) {
+      int kr = 2 * kk + (lane >> 5);
+      float a0 = Ds[kr][lane & 31];
+      float a1 = Ds[kr][32 + (lane & 31)];
+      float b = Ac[kr][w * 32 + (lane & 31)];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+    }
+    if (nt == 0 && t < 64) {
+#pragma unroll 8
+      for (int k = 0; k < DW_RK; ++k) bsum += Ds[k][t];
+    }
+    __syncthreads();
+  }
+  float *slab = slabs + (int64_t)blockIdx.x * ((int64_t)Fo * K2 + Fo);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int mrow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    int ncol = c0 + w * 32 + (lane & 31);
+    slab[(int64_t)(m0 + mrow) * K2 + ncol] = acc0[r];
+    slab[(int64_t)(m0 + 32 + mrow) * K2 + ncol] = acc1[r];
+  }
+  if (nt == 0 && t < 64) slab[(int64_t)Fo * K2 + m0 + t] = bsum;
+}
+
+// =============================================================================== VALU
+// small-K forward (2*Fi <= 16, Fo <= 64): wave per row, lane = output column, weights in
+// registers, the row's 2*Fi inputs fetched by one load and broadcast with v_readlane.
+template <int K2MAX>
+__global__ void __launch_bounds__(256)
+project_fwd_smallk_k(const float *__restrict__ agg, const float *__restrict__ x,
+                     const float *__restrict__ wt, int64_t N, int Fi, int Fo, EpiArgs e,
+                     float *__restrict__ out) {
+  const int lane = gs_lane();
+  const int K2 = 2 * Fi;
+  float wreg[K2MAX];
+#pragma unroll
+  for (int k = 0; k < K2MAX; ++k) wreg[k] = (k < K2 && lane < Fo) ? wt[k * Fo + lane] : 0.f;
+  const float bias = lane < Fo ? e.bias[lane] : 0.f;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = wave0; row < N; row += nwaves) {
+    float in = 0.f;
+    if (lane < Fi) in = agg[row * Fi + lane];
+    else if (lane < K2) in = x[row * Fi + lane - Fi];
+    float v = bias;
+#pragma unroll
+    for (int k = 0; k < K2MAX; ++k) {
+      float ak = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, in), k));
+      v = fmaf(ak, wreg[k], v);
+    }
+    if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) v = fmaxf(v, 0.f);
+    if (e.mode == GSAGE_EPI_RELU_DROPOUT && lane < Fo) {
+      uint64_t idx = (uint64_t)row * (uint64_t)Fo + (uint64_t)lane;
+      bool keep = e.keep_mask ? (e.keep_mask[idx] != 0) : dropout_keep(e.seed, idx, e.p);
+      v = keep ? v * e.inv_keep : 0.f;
+    }
+    if (e.mode == GSAGE_EPI_L2NORM) {
+      float ss = gs_wave_sum(lane < Fo ? v * v : 0.f);
+      float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
+      v *= rn;
+      if (lane == 0 && e.rnorm) e.rnorm[row] = rn;
+    }
+    if (lane < Fo) out[row * Fo + lane] = v;
+  }
+}
+
+// generic forward: wave per row, lanes stride the output columns; Wt from L1/L2.
+__global__ void __launch_bounds__(256)
+project_fwd_generic_k(const float *__restrict__ agg, const float *__restrict__ x,
+                      const float *__restrict__ wt, int64_t N, int Fi, int Fo, EpiArgs e,
+                      float *out) {
+  const int lane = gs_lane();
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = wave0; row < N; row += nwaves) {
+    const float *ar = agg + row * Fi, *xr = x + row * Fi;
+    float ss = 0.f;
+    for (int j = lane; j < Fo; j += 64) {
+      float v = e.bias[j];
+      for (int k = 0; k < Fi; ++k) v = fmaf(ar[k], wt[k * Fo + j], v);
+      for (int k = 0; k < Fi; ++k) v = fmaf(xr[k], wt[(Fi + k) * Fo + j], v);
+      if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) v = fmaxf(v, 0.f);
+      if (e.mode == GSAGE_EPI_RELU_DROPOUT) {
+        uint64_t idx = (uint64_t)row * (uint64_t)Fo + (uint64_t)j;
+        bool keep = e.keep_mask ? (e.keep_mask[idx] != 0) : dropout_keep(e.seed, idx, e.p);
+        v = keep ? v * e.inv_keep : 0.f;
+      }
+      ss += v * v;
+      out[row * Fo + j] = v;
+    }
+    if (e.mode == GSAGE_EPI_L2NORM) {
+      ss = gs_wave_sum(ss);
+      float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
+      for (int j = lane; j < Fo; j += 64) out[row * Fo + j] *= rn;  // same lane wrote it
+      if (lane == 0 && e.rnorm) e.rnorm[row] = rn;
+    }
+  }
+}
+
+// ------------------------------------------------------------------- epilogue backward
+// dpre = d loss / d (pre-epilogue activations); wave per row.
+__global__ void __launch_bounds__(256)
+epilogue_bwd_k(const float *__restrict__ g, const float *__restrict__ out,
+               const float *__restrict__ rnorm, int64_t N, int Fo, int mode, float inv_keep,
+               float *__restrict__ dpre) {
+  const int lane = gs_lane();
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = wave0; row < N; row += nwaves) {
+    const float *gr = g + row * Fo, *yr = out + row * Fo;
+    float *dr = dpre + row * Fo;
+    if (mode == GSAGE_EPI_L2NORM) {
+      float rn = rnorm[row];
+      if (rn >= 0.5f / L2_EPS) {  // norm was clamped to eps: y = x/eps, dy/dx = I/eps
+        for (int j = lane; j < Fo; j += 64) dr[j] = gr[j] * rn;
+      } else {
+        float dot = 0.f;
+        for (int j = lane; j < Fo; j += 64) dot = fmaf(gr[j], yr[j], dot);
+        dot = gs_wave_sum(dot);
+        for (int j = lane; j < Fo; j += 64) dr[j] = (gr[j] - yr[j] * dot) * rn;
+      }
+    } else {  // RELU / RELU_DROPOUT: out > 0 <=> pre > 0 and kept
+      for (int j = lane; j < Fo; j += 64) dr[j] = yr[j] > 0.f ? gr[j] * inv_keep : 0.f;
+    }
+  }
+}
+
+// generic dX: wave per row, lanes stride the input columns.
+__global__ void __launch_bounds__(256)
+dx_generic_k(const float *__restrict__ dpre, const float *__restrict__ wl,
+             const float *__restrict__ wr, const float *__restrict__ agg_scale, int64_t N,
+             int Fi, int Fo, float *__restrict__ grad_agg, float *__restrict__ grad_x) {
+  const int lane = gs_lane();
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = wave0; row < N; row += nwaves) {
+    const float *dr = dpre + row * Fo;
+    float s = agg_scale ? agg_scale[row] : 1.f;
+    for (int k = lane; k < Fi; k += 64) {
+      float ga = 0.f, gx = 0.f;
+      for (int j = 0; j < Fo; ++j) {
+        float d = dr[j];
+        ga = fmaf(d, wl[j * Fi + k], ga);
+        gx = fmaf(d, wr[j * Fi + k], gx);
+      }
+      if (grad_agg) grad_agg[row * Fi + k] = ga * s;
+      if (grad_x) grad_x[row * Fi + k] = gx;
+    }
+  }
+}
+
+// small-K dW (2*Fi <= 16, Fo <= 64): lane = output row m of dW, K2MAX accumulators.
+template <int K2MAX>
+__global__ void __launch_bounds__(256)
+dw_smallk_k(const float *__restrict__ dpre, const float *__restrict__ agg,
+            const float *__restrict__ x, int64_t M, int Fi, int Fo, int64_t rows_per_block,
+            float *__restrict__ slabs) {
+  __shared__ float red[4][K2MAX + 1][64];
+  const int lane = gs_lane(), w = threadIdx.x >> 6;
+  const int K2 = 2 * Fi;
+  int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > M) r_end = M;
+  float acc[K2MAX + 1];
+#pragma unroll
+  for (int k = 0; k <= K2MAX; ++k) acc[k] = 0.f;
+  for (int64_t row = r_begin + w; row < r_end; row += 4) {
+    float d = lane < Fo ? dpre[row * Fo + lane] : 0.f;
+    float in = 0.f;
+    if (lane < Fi) in = agg[row * Fi + lane];
+    else if (lane < K2) in = x[row * Fi + lane - Fi];
+#pragma unroll
+    for (int k = 0; k < K2MAX; ++k) {
+      float ak = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, in), k));
+      acc[k] = fmaf(d, ak, acc[k]);
+    }
+    acc[K2MAX] += d;
+  }
+#pragma unroll
+  for (int k = 0; k <= K2MAX; ++k) red[w][k][lane] = acc[k];
+  __syncthreads();
+  float *slab = slabs + (int64_t)blockIdx.x * ((int64_t)Fo * K2 + Fo);
+  for (int e = threadIdx.x; e < (K2MAX + 1) * 64; e += 256) {
+    int k = e / 64, m = e % 64;
+    float s = red[0][k][m] + red[1][k][m] + red[2][k][m] + red[3][k][m];
+    if (m < Fo) {
+      if (k < K2) slab[(int64_t)m * K2 + k] = s;
+      else if (k == K2MAX) slab[(int64_t)Fo * K2 + m] = s;
+    }
+  }
+}
+
+// generic dW: thread per output element, rows of the block's chunk in order.
+__global__ void __launch_bounds__(256)
+dw_generic_k(const float *__restrict__ dpre, const float *__restrict__ agg,
+             const float *__restrict__ x, int64_t M, int Fi, int Fo, int64_t rows_per_block,
+             float *__restrict__ slabs) {
+  const int K2 = 2 * Fi;
+  int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_begin + rows_per_block;
+  if (r_end > M) r_end = M;
+  float *slab = slabs + (int64_t)blockIdx.x * ((int64_t)Fo * K2 + Fo);
+  const int total = Fo * K2 + Fo;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    float s = 0.f;
+    if (e < Fo * K2) {
+      int m = e / K2, k = e % K2;
+      const float *src = k < Fi ? agg + k : x + (k - Fi);
+      for (int64_t row = r_begin; row < r_end; ++row) s = fmaf(dpre[row * Fo + m], src[row * Fi], s);
+    } else {
+      int m = e - Fo * K2;
+      for (int64_t row = r_begin; row < r_end; ++row) s += dpre[row * Fo + m];
+    }
+    slab[e] = s;
+  }
+}
+
+// sum the slabs in order and split into grad_W_l, grad_W_r, grad_b
+__global__ void reduce_slabs_k(const float *__restrict__ slabs, int nslab, int Fi, int Fo,
+                               float *__restrict__ gwl, float *__restrict__ gwr,
+                               float *__restrict__ gb) {
+  const int K2 = 2 * Fi;
+  const int total = Fo * K2 + Fo;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < nslab; ++b) s += slabs[(int64_t)b * total + e];
+    if (e < Fo * K2) {
+      int m = e / K2, k = e % K2;
+      if (k < Fi) gwl[m * Fi + k] = s;
+      else gwr[m * Fi + k - Fi] = s;
+    } else {
+      gb[e - Fo * K2] = s;
+    }
+  }
+}
+
+bool mfma_dim(int64_t f) { return f == 64 || f == 128 || f == 256; }
+
+int num_slabs(int64_t N) {
+  int64_t s = (N + 255) / 256;
+  if (s < 1) s = 1;
+  if (s > 1024) s = 1024;
+  return (int)s;
+}
+
+}  // namespace
+
+extern "C" size_t gsage_project_workspace_bytes(int64_t Fi, int64_t Fo) {
+  if (Fi <= 0 || Fo <= 0) return 0;
+  return gs_align_up((size_t)(2 * Fi * Fo) * sizeof(float), 256);
+}
+
+extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *w_l,
+                                 const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                                 int64_t Fo, int epilogue, const uint8_t *keep_mask,
+                                 uint64_t seed, float p, float *out, float *rnorm, void *wpack,
+                                 int force_generic, gsage_stream_t stream) {
+  if (N < 0 || Fi <= 0 || Fo <= 0 || !agg || !x || !w_l || !b_l || !w_r || !out || !wpack)
+    return GSAGE_ERR_INVALID_ARG;
+  if (epilogue < GSAGE_EPI_NONE || epilogue > GSAGE_EPI_L2NORM) return GSAGE_ERR_INVALID_ARG;
+  if (epilogue == GSAGE_EPI_RELU_DROPOUT && !(p >= 0.f && p < 1.f)) return GSAGE_ERR_INVALID_ARG;
+  if (Fi > 16384 || Fo > 16384) return GSAGE_ERR_UNSUPPORTED;
+  if (N == 0) return GSAGE_OK;
+  hipStream_t st = gs_stream(stream);
+  EpiArgs e{};
+  e.mode = epilogue;
+  e.bias = b_l;
+  e.keep_mask = keep_mask;
+  e.seed = seed;
+  e.p = p;
+  e.inv_keep = epilogue == GSAGE_EPI_RELU_DROPOUT ? 1.0f / (1.0f - p) : 1.0f;
+  e.rnorm = rnorm;
+  e.row_scale = nullptr;
+  float *wp = (float *)wpack;
+  const int fi = (int)Fi, fo = (int)Fo;
+  const int pack_grid = gs_grid(2 * Fi * Fo, 256, 64);
+  const bool aligned = (((uintptr_t)agg | (uintptr_t)x | (uintptr_t)out | (uintptr_t)b_l |
+                         (uintptr_t)keep_mask) & 15) == 0;
+  if (!force_generic && aligned && mfma_dim(Fi) && mfma_dim(Fo)) {
+    hipLaunchKernelGGL(pack_fwd_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
+    GemmArgs a{};
+    a.A1 = agg; a.A2 = x; a.Bp = wp; a.C1 = out; a.C2 = nullptr;
+    a.M = N; a.K1 = fi; a.K = 2 * fi; a.N1 = fo; a.Ncols = fo; a.epi = e;
+    return launch_gemm_bn(fo, a, st);
+  }
+  hipLaunchKernelGGL(pack_t_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
+  int grid = gs_grid(N, 4, 256 * 16);
+  if (2 * Fi <= 16 && Fo <= 64)
+    hipLaunchKernelGGL((project_fwd_smallk_k<16>), dim3(grid), dim3(256), 0, st, agg, x, wp, N, fi,
+                       fo, e, out);
+  else
+    hipLaunchKernelGGL(project_fwd_generic_k, dim3(grid), dim3(256), 0, st, agg, x, wp, N, fi, fo,
+                       e, out);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}
+
+extern "C" size_t gsage_project_bwd_workspace_bytes(int64_t N, int64_t Fi, int64_t Fo) {
+  if (N < 0 || Fi <= 0 || Fo <= 0) return 0;
+  size_t pack = gs_align_up((size_t)(2 * Fi * Fo) * sizeof(float), 256);
+  size_t slabs = gs_align_up((size_t)num_slabs(N) * (size_t)(2 * Fi * Fo + Fo) * sizeof(float), 256);
+  return pack + slabs;
+}
+
+extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const float *rnorm,
+                                 const float *agg, const float *x, const float *w_l,
+                                 const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
+                                 int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
+                                 float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
+                                 void *ws, size_t ws_bytes, int force_generic,
+                                 gsage_stream_t stream) {
+  if (N < 0 || Fi <= 0 || Fo <= 0 || !grad_out || !agg || !x || !w_l || !w_r || !grad_w_l ||
+      !grad_b || !grad_w_r || !ws)
+    return GSAGE_ERR_INVALID_ARG;
+  if (epilogue < GSAGE_EPI_NONE || epilogue > GSAGE_EPI_L2NORM) return GSAGE_ERR_INVALID_ARG;
+  if (epilogue != GSAGE_EPI_NONE && (!out || !dpre)) return GSAGE_ERR_INVALID_ARG;
+  if (epilogue == GSAGE_EPI_L2NORM && !rnorm) return GSAGE_ERR_INVALID_ARG;
+  if (Fi > 16384 || Fo > 16384) return GSAGE_ERR_UNSUPPORTED;
+  if (ws_bytes < gsage_project_bwd_workspace_bytes(N, Fi, Fo)) return GSAGE_ERR_WORKSPACE;
+  hipStream_t st = gs_stream(stream);
+  const int fi = (int)Fi, fo = (int)Fo;
+  float *wp = (float *)ws;
+  float *slabs = (float *)((char *)ws + gs_align_up((size_t)(2 * Fi * Fo) * sizeof(float), 256));
+  const int nslab = num_slabs(N);
+
+  if (N == 0) {
+    if (hipMemsetAsync(grad_w_l, 0, (size_t)Fi * Fo * 4, st) != hipSuccess ||
+        hipMemsetAsync(grad_w_r, 0, (size_t)Fi * Fo * 4, st) != hipSuccess ||
+        hipMemsetAsync(grad_b, 0, (size_t)Fo * 4, st) != hipSuccess)
+      return GSAGE_ERR_LAUNCH;
+    return GSAGE_OK;
+  }
+
+  // 1. dpre
+  const float *dp = grad_out;
+  if (epilogue != GSAGE_EPI_NONE) {
+    float inv_keep = epilogue == GSAGE_EPI_RELU_DROPOUT ? 1.0f / (1.0f - p) : 1.0f;
+    hipLaunchKernelGGL(epilogue_bwd_k, dim3(gs_grid(N, 4, 256 * 16)), dim3(256), 0, st, grad_out,
+                       out, rnorm, N, fo, epilogue, inv_keep, dpre);
+    GSAGE_CHECK_LAUNCH();
+    dp = dpre;
+  }
+  const bool aligned = (((uintptr_t)dp | (uintptr_t)agg | (uintptr_t)x | (uintptr_t)grad_agg |
+                         (uintptr_t)grad_x) & 15) == 0;
+  const bool mfma = !force_generic && aligned && mfma_dim(Fi) && mfma_dim(Fo);
+
+  // 2. input gradients
+  if (grad_agg || grad_x) {
+    if (mfma && grad_agg && grad_x) {
+      hipLaunchKernelGGL(pack_dx_k, dim3(gs_grid(2 * Fi * Fo, 256, 64)), dim3(256), 0, st, w_l, w_r,
+                         fi, fo, wp);
+      GemmArgs a{};
+      a.A1 = dp; a.A2 = nullptr; a.Bp = wp; a.C1 = grad_agg; a.C2 = grad_x;
+      a.M = N; a.K1 = fo; a.K = fo; a.N1 = fi; a.Ncols = 2 * fi;
+      a.epi.mode = MODE_DX;
+      a.epi.row_scale = agg_scale;
+      int rc = launch_gemm_bn(fi, a, st);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(dx_generic_k, dim3(gs_grid(N, 4, 256 * 16)), dim3(256), 0, st, dp, w_l,
+                         w_r, agg_scale, N, fi, fo, grad_agg, grad_x);
+      GSAGE_CHECK_LAUNCH();
+    }
+  }
+
+  // 3. weight gradients: partial slabs, then an ordered sum
+  int64_t rpb = (N + nslab - 1) / nslab;
+  rpb = (rpb + DW_RK - 1) / DW_RK * DW_RK;
+  if (mfma) {
+    dim3 grid((unsigned)nslab, (unsigned)((fo / 64) * (2 * fi / 128)));
+    hipLaunchKernelGGL(dw_mfma_k, grid, dim3(256), 0, st, dp, agg, x, N, fi, fo, rpb, slabs);
+  } else if (2 * Fi <= 16 && Fo <= 64) {
+    hipLaunchKernelGGL((dw_smallk_k<16>), dim3(nslab), dim3(256), 0, st, dp, agg, x, N, fi, fo, rpb,
+                       slabs);
+  } else {
+    hipLaunchKernelGGL(dw_generic_k, dim3(nslab), dim3(256), 0, st, dp, agg, x, N, fi, fo, rpb,
+                       slabs);
+  }
+  GSAGE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_slabs_k, dim3(gs_grid(2 * Fi * Fo + Fo, 256, 256)), dim3(256), 0, st,
+                     slabs, nslab, fi, fo, grad_w_l, grad_w_r, grad_b);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}

@@ -1,0 +1,115 @@
+"""Graph structure cache: both CSR orientations of an ``edge_index`` on the device.
+
+The reference rebuilds the scatter bookkeeping implicitly inside PyG on every
+forward (``src/model/graphsage.py:133,138``).  Here it is built once per graph by the
+K1 kernels (``gsage_csr_build``) and reused by every layer, forward and backward.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class GraphCSR:
+    num_nodes: int
+    num_edges: int
+    rowptr: torch.Tensor      # int32 [N+1]  in-edges grouped by target
+    col: torch.Tensor         # int32 [E]    sources, stable edge order inside a row
+    rowptr_t: torch.Tensor    # int32 [N+1]  out-edges grouped by source
+    col_t: torch.Tensor       # int32 [E]    targets
+    inv_deg: torch.Tensor     # fp32  [N]    1 / max(in_degree, 1)
+    long_rows: torch.Tensor   # int32 [cap]  hub rows of (rowptr, col)
+    long_rows_t: torch.Tensor  # int32 [cap]  hub rows of (rowptr_t, col_t)
+    n_long: torch.Tensor      # int32 [2]
+    status: torch.Tensor      # int32 [1]    device flag word
+
+    def in_degree(self) -> torch.Tensor:
+        return (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+
+    def out_degree(self) -> torch.Tensor:
+        return (self.rowptr_t[1:] - self.rowptr_t[:-1]).to(torch.int64)
+
+
+def build_csr(edge_index: torch.Tensor, num_nodes: int, check: bool = True) -> GraphCSR:
+    """int64 ``[2,E]`` (row 0 = source, row 1 = target) -> :class:`GraphCSR`.
+
+    ``check=True`` reads the device flag word once (one host sync per graph) and raises
+    ``IndexError`` if any index lies outside ``[0, num_nodes)``.
+    """
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
+    if edge_index.dtype != torch.int64:
+        raise ValueError(f"edge_index must be int64, got {edge_index.dtype}")
+    if not edge_index.is_cuda:
+        raise ValueError("graphsage_amd runs on the GPU only: edge_index must be a CUDA/HIP tensor")
+    lib = _lib.load()
+    ei = edge_index.contiguous()
+    dev = ei.device
+    E, N = int(ei.size(1)), int(num_nodes)
+    i32 = dict(dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rowptr = torch.empty(N + 1, **i32)
+        rowptr_t = torch.empty(N + 1, **i32)
+        col = torch.empty(max(E, 1), **i32)
+        col_t = torch.empty(max(E, 1), **i32)
+        inv_deg = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        cap = E // max(lib.gsage_long_row_threshold(), 1) + 1
+        long_rows = torch.empty(cap, **i32)
+        long_rows_t = torch.empty(cap, **i32)
+        n_long = torch.zeros(2, **i32)
+        status = torch.zeros(1, **i32)
+        ws_bytes = lib.gsage_csr_workspace_bytes(E, N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = lib.gsage_csr_build(ei.data_ptr(), E, N, rowptr.data_ptr(), col.data_ptr(),
+                                 rowptr_t.data_ptr(), col_t.data_ptr(), inv_deg.data_ptr(),
+                                 long_rows.data_ptr(), long_rows_t.data_ptr(), cap,
+                                 n_long.data_ptr(), status.data_ptr(), ws.data_ptr(), ws_bytes,
+                                 _lib.stream_handle())
+        _lib.check(rc, "gsage_csr_build")
+        if check and int(status.item()) & _lib.FLAG_INDEX_OUT_OF_RANGE:
+            raise IndexError(f"edge_index holds node ids outside [0, {N})")
+        del ws
+    return GraphCSR(N, E, rowptr, col[:E], rowptr_t, col_t[:E], inv_deg[:N], long_rows,
+                    long_rows_t, n_long, status)
+
+
+class GraphCache:
+    """Keeps the CSR of the graphs recently seen, keyed on the identity of the
+    ``edge_index`` tensor (pointer, shape, in-place version counter, device)."""
+
+    def __init__(self, capacity: int = 4):
+        self.capacity = capacity
+        self._store: Dict[Tuple, GraphCSR] = {}
+
+    @staticmethod
+    def _key(edge_index: torch.Tensor, num_nodes: int) -> Tuple:
+        return (edge_index.data_ptr(), tuple(edge_index.shape), tuple(edge_index.stride()),
+                edge_index._version, str(edge_index.device), int(num_nodes))
+
+    def get(self, edge_index: torch.Tensor, num_nodes: int) -> GraphCSR:
+        k = self._key(edge_index, num_nodes)
+        g = self._store.get(k)
+        if g is None:
+            g = build_csr(edge_index, num_nodes)
+            if len(self._store) >= self.capacity:
+                self._store.pop(next(iter(self._store)))
+            self._store[k] = g
+        return g
+
+    def clear(self) -> None:
+        self._store.clear()
+
+
+_default_cache: Optional[GraphCache] = None
+
+
+def default_cache() -> GraphCache:
+    global _default_cache
+    if _default_cache is None:
+        _default_cache = GraphCache()
+    return _default_cache

@@ -1,0 +1,133 @@
+"""Drop-in ``GraphSAGE`` for the reference's ``src/model/graphsage.py``.
+
+Same constructor, attributes, ``forward(x, edge_index)`` contract and ``state_dict``
+layout as the reference class (``src/model/graphsage.py:68-157``), whose layers are
+``torch_geometric.nn.SAGEConv`` (parameters ``convs.{i}.lin_l.weight [out,in]``,
+``convs.{i}.lin_l.bias [out]``, ``convs.{i}.lin_r.weight [out,in]``).  Every layer runs as
+CSR segment-mean (K2) + fused projection (K3) on the MI355X; ReLU/dropout of the hidden
+layers (``:134-135``) and the final ``F.normalize`` (``:141-142``) are epilogues of K3.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .graph import GraphCSR, default_cache
+from .ops import SAGELayerFunction
+
+
+class SAGEConv(nn.Module):
+    """Mean-aggregating SAGEConv: ``lin_l(mean_{j->i} x_j) + lin_r(x_i)``.
+
+    Stands in for ``torch_geometric.nn.SAGEConv(in, out, aggr='mean')`` with PyG's
+    defaults (root_weight=True, bias=True, normalize=False, project=False) and PyG's
+    parameter names; initialisation is ``nn.Linear``'s (Kaiming-uniform, a=sqrt(5)).
+    """
+
+    def __init__(self, in_channels: int, out_channels: int, aggr: str = "mean"):
+        super().__init__()
+        if aggr != "mean":
+            raise ValueError(f"Unknown aggregator: {aggr!r} (the MI355X hot path implements 'mean')")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.aggr = aggr
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+    def reset_parameters(self) -> None:
+        self.lin_l.reset_parameters()
+        self.lin_r.reset_parameters()
+
+    def run(self, x: torch.Tensor, graph: GraphCSR, epilogue: int = _lib.EPI_NONE, p: float = 0.0,
+            seed: int = 0, keep_mask: Optional[torch.Tensor] = None,
+            force_generic: bool = False) -> torch.Tensor:
+        return SAGELayerFunction.apply(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight,
+                                       graph, epilogue, p, seed, keep_mask, force_generic)
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+        graph = default_cache().get(edge_index, x.size(0))
+        return self.run(x, graph)
+
+    def extra_repr(self) -> str:
+        return f"{self.in_channels}, {self.out_channels}, aggr={self.aggr}"
+
+
+class GraphSAGE(nn.Module):
+    """GraphSAGE encoder (reference ``GraphSAGE``, ``src/model/graphsage.py:33-157``)."""
+
+    def __init__(self, in_channels: int = 7, hidden_channels: int = 64, out_channels: int = 64,
+                 num_layers: int = 2, dropout: float = 0.3, aggregator: str = "mean",
+                 normalize_output: bool = True):
+        super().__init__()
+        self.in_channels = in_channels
+        self.hidden_channels = hidden_channels
+        self.out_channels = out_channels
+        self.num_layers = num_layers
+        self.dropout_rate = dropout
+        self.normalize_output = normalize_output
+
+        self.convs = nn.ModuleList()
+        self.convs.append(SAGEConv(in_channels, hidden_channels, aggr=aggregator))
+        for _ in range(num_layers - 2):
+            self.convs.append(SAGEConv(hidden_channels, hidden_channels, aggr=aggregator))
+        if num_layers > 1:
+            self.convs.append(SAGEConv(hidden_channels, out_channels, aggr=aggregator))
+        # kept for API parity (reference attribute `dropout`); the mask itself is drawn
+        # inside the K3 epilogue, not by this module
+        self.dropout = nn.Dropout(dropout)
+        self._force_generic = False
+
+    def _dropout_seed(self) -> int:
+        # CPU generator: reproducible under torch.manual_seed, no device sync
+        return int(torch.empty((), dtype=torch.int64).random_().item())
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor,
+                keep_masks: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        """x: fp32 [N, in_channels]; edge_index: int64 [2, E] -> fp32 [N, out_channels].
+
+        ``keep_masks`` (optional, one uint8 [N, hidden] tensor per hidden layer) injects the
+        dropout masks instead of drawing them in the kernel (parity tests).
+        """
+        graph = default_cache().get(edge_index, x.size(0))
+        p = float(self.dropout_rate)
+        training = self.training and p > 0.0
+        for i, conv in enumerate(self.convs[:-1]):
+            if training:
+                km = keep_masks[i] if keep_masks is not None else None
+                seed = 0 if km is not None else self._dropout_seed()
+                x = conv.run(x, graph, _lib.EPI_RELU_DROPOUT, p, seed, km, self._force_generic)
+            else:
+                x = conv.run(x, graph, _lib.EPI_RELU, 0.0, 0, None, self._force_generic)
+        epi = _lib.EPI_L2NORM if self.normalize_output else _lib.EPI_NONE
+        return self.convs[-1].run(x, graph, epi, 0.0, 0, None, self._force_generic)
+
+    def get_embedding_dim(self) -> int:
+        return self.out_channels
+
+    def reset_parameters(self) -> None:
+        for conv in self.convs:
+            conv.reset_parameters()
+
+    def count_parameters(self) -> int:
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+
+def create_model(config: dict, device: Optional[torch.device] = None) -> GraphSAGE:
+    """Counterpart of ``create_model`` (``src/model/graphsage.py:299-325``)."""
+    model_cfg = config.get("model", {})
+    feat_cfg = config.get("features", {})
+    model = GraphSAGE(
+        in_channels=feat_cfg.get("dimensions", 7),
+        hidden_channels=model_cfg.get("hidden_dim", 64),
+        out_channels=model_cfg.get("output_dim", 64),
+        num_layers=model_cfg.get("num_layers", 2),
+        dropout=model_cfg.get("dropout", 0.3),
+        aggregator=model_cfg.get("aggregator", "mean"),
+        normalize_output=model_cfg.get("normalize_output", True),
+    )
+    if device is not None:
+        model = model.to(device)
+    return model

@@ -1,0 +1,214 @@
+"""Thin Python wrappers over the C ABI plus the two ``autograd.Function``s.
+
+PyTorch owns every buffer (inputs, outputs, saved tensors, workspaces) and supplies
+the stream; all arithmetic happens in libgsage.so.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import EPI_L2NORM, EPI_NONE, EPI_RELU, EPI_RELU_DROPOUT
+from .graph import GraphCSR
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (graphsage_amd has no CPU path)")
+    return t.contiguous()
+
+
+def _i64c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.int64:
+        raise ValueError(f"{name} must be int64, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (graphsage_amd has no CPU path)")
+    return t.contiguous()
+
+
+# ----------------------------------------------------------------------------- raw ops
+def segment_gather(rowptr, col, x, row_scale=None, edge_weight=None, add_to=None, out=None,
+                   long_rows=None, n_long=None) -> torch.Tensor:
+    """out[i] = add_to[i] + row_scale[i] * sum_p edge_weight[col[p]] * x[col[p]] (K2/K7)."""
+    lib = _lib.load()
+    x = _f32c(x, "x")
+    N, F = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.gsage_segment_gather(rowptr.data_ptr(), col.data_ptr(), _lib.ptr(row_scale),
+                                      _lib.ptr(edge_weight), x.data_ptr(), _lib.ptr(add_to),
+                                      N, F, out.data_ptr(), _lib.ptr(long_rows),
+                                      _lib.ptr(n_long), _lib.stream_handle())
+    _lib.check(rc, "gsage_segment_gather")
+    return out
+
+
+def aggregate_mean(graph: GraphCSR, x: torch.Tensor) -> torch.Tensor:
+    """SAGEConv mean aggregation (forward, K2)."""
+    return segment_gather(graph.rowptr, graph.col, x, row_scale=graph.inv_deg,
+                          long_rows=graph.long_rows, n_long=graph.n_long[0:1])
+
+
+def aggregate_mean_bwd(graph: GraphCSR, grad_agg: torch.Tensor, prescaled: bool = False,
+                       add_to: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """grad_x[j] = add_to[j] + sum_{i in out(j)} grad_agg[i] * inv_deg[i] (K7)."""
+    out = add_to if add_to is not None else None
+    return segment_gather(graph.rowptr_t, graph.col_t, grad_agg,
+                          edge_weight=None if prescaled else graph.inv_deg, add_to=add_to,
+                          out=out, long_rows=graph.long_rows_t, n_long=graph.n_long[1:2])
+
+
+def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0, p=0.0,
+                force_generic=False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    lib = _lib.load()
+    N, Fi = x.shape
+    Fo = w_l.shape[0]
+    dev = x.device
+    with torch.cuda.device(dev):
+        out = torch.empty(N, Fo, dtype=torch.float32, device=dev)
+        rnorm = torch.empty(N, dtype=torch.float32, device=dev) if epilogue == EPI_L2NORM else None
+        wpack = torch.empty(lib.gsage_project_workspace_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        if keep_mask is not None:
+            if keep_mask.dtype != torch.uint8 or tuple(keep_mask.shape) != (N, Fo):
+                raise ValueError("keep_mask must be uint8 [N, Fo]")
+            keep_mask = keep_mask.contiguous()
+        rc = lib.gsage_project_fwd(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), b_l.data_ptr(),
+                                   w_r.data_ptr(), N, Fi, Fo, int(epilogue), _lib.ptr(keep_mask),
+                                   int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), out.data_ptr(),
+                                   _lib.ptr(rnorm), wpack.data_ptr(), int(force_generic),
+                                   _lib.stream_handle())
+    _lib.check(rc, "gsage_project_fwd")
+    return out, rnorm
+
+
+def project_bwd(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue, p,
+                need_input_grad: bool, force_generic=False):
+    lib = _lib.load()
+    N, Fi = x.shape
+    Fo = w_l.shape[0]
+    dev = x.device
+    with torch.cuda.device(dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        dpre = torch.empty(N, Fo, **f32) if epilogue != EPI_NONE else None
+        grad_agg = torch.empty(N, Fi, **f32) if need_input_grad else None
+        grad_x = torch.empty(N, Fi, **f32) if need_input_grad else None
+        gwl = torch.empty(Fo, Fi, **f32)
+        gwr = torch.empty(Fo, Fi, **f32)
+        gb = torch.empty(Fo, **f32)
+        ws_bytes = lib.gsage_project_bwd_workspace_bytes(N, Fi, Fo)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = lib.gsage_project_bwd(grad_out.data_ptr(), _lib.ptr(out), _lib.ptr(rnorm),
+                                   agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), w_r.data_ptr(),
+                                   _lib.ptr(agg_scale), N, Fi, Fo, int(epilogue), float(p),
+                                   _lib.ptr(dpre), _lib.ptr(grad_agg), _lib.ptr(grad_x),
+                                   gwl.data_ptr(), gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(),
+                                   ws_bytes, int(force_generic), _lib.stream_handle())
+    _lib.check(rc, "gsage_project_bwd")
+    return grad_agg, grad_x, gwl, gb, gwr
+
+
+def skipgram_fwd(emb, targets, contexts, negatives, scale, norm_b=None, norm_bk=None):
+    lib = _lib.load()
+    N, D = emb.shape
+    B = targets.numel()
+    K = negatives.shape[1] if negatives.dim() == 2 else 0
+    dev = emb.device
+    if norm_b is None:
+        norm_b = float(B)
+    if norm_bk is None:
+        norm_bk = float(B * K) if K > 0 else 1.0
+    with torch.cuda.device(dev):
+        coef = torch.empty(B, 1 + K, dtype=torch.float32, device=dev)
+        stats = torch.empty(8, dtype=torch.float32, device=dev)
+        ws_bytes = lib.gsage_skipgram_workspace_bytes(B)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = lib.gsage_skipgram_fwd(emb.data_ptr(), N, D, targets.data_ptr(), contexts.data_ptr(),
+                                    negatives.data_ptr() if K > 0 else None, B, K, float(scale),
+                                    float(norm_b), float(norm_bk), coef.data_ptr(),
+                                    stats.data_ptr(), ws.data_ptr(), ws_bytes,
+                                    _lib.stream_handle())
+    _lib.check(rc, "gsage_skipgram_fwd")
+    return coef, stats
+
+
+def skipgram_bwd(emb, targets, contexts, negatives, coef, grad_loss, grad_emb=None):
+    lib = _lib.load()
+    N, D = emb.shape
+    B = targets.numel()
+    K = coef.shape[1] - 1
+    with torch.cuda.device(emb.device):
+        if grad_emb is None:
+            grad_emb = torch.zeros_like(emb)
+        rc = lib.gsage_skipgram_bwd(emb.data_ptr(), N, D, targets.data_ptr(), contexts.data_ptr(),
+                                    negatives.data_ptr() if K > 0 else None, B, K, coef.data_ptr(),
+                                    grad_loss.data_ptr(), grad_emb.data_ptr(),
+                                    _lib.stream_handle())
+    _lib.check(rc, "gsage_skipgram_bwd")
+    return grad_emb
+
+
+# -------------------------------------------------------------------------- autograd glue
+class SAGELayerFunction(torch.autograd.Function):
+    """One SAGEConv layer with a fused epilogue: K2 + K3 forward, K3' + K7 backward."""
+
+    @staticmethod
+    def forward(ctx, x, w_l, b_l, w_r, graph: GraphCSR, epilogue: int, p: float, seed: int,
+                keep_mask, force_generic: bool):
+        x = _f32c(x, "x")
+        w_l, b_l, w_r = _f32c(w_l, "lin_l.weight"), _f32c(b_l, "lin_l.bias"), _f32c(w_r, "lin_r.weight")
+        if x.dim() != 2 or x.size(0) != graph.num_nodes:
+            raise ValueError(f"x must be [num_nodes={graph.num_nodes}, F], got {tuple(x.shape)}")
+        if w_l.shape != w_r.shape or w_l.size(1) != x.size(1) or b_l.numel() != w_l.size(0):
+            raise ValueError("SAGEConv weight shapes do not match the input width")
+        agg = aggregate_mean(graph, x)
+        out, rnorm = project_fwd(agg, x, w_l, b_l, w_r, epilogue, keep_mask, seed, p, force_generic)
+        ctx.graph, ctx.epilogue, ctx.p, ctx.force_generic = graph, epilogue, p, force_generic
+        ctx.save_for_backward(x, agg, out, rnorm, w_l, w_r)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, agg, out, rnorm, w_l, w_r = ctx.saved_tensors
+        graph = ctx.graph
+        need_x = ctx.needs_input_grad[0]
+        grad_out = _f32c(grad_out, "grad_out")
+        grad_agg, grad_x, gwl, gb, gwr = project_bwd(
+            grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p,
+            need_x, ctx.force_generic)
+        if need_x:
+            # grad_agg arrives pre-scaled by inv_deg[row]; gather it over the transposed CSR
+            grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x)
+        return grad_x, gwl, gb, gwr, None, None, None, None, None, None
+
+
+class SkipGramFunction(torch.autograd.Function):
+    """K4 forward / K5 backward.  Returns (loss 0-dim, stats[8])."""
+
+    @staticmethod
+    def forward(ctx, emb, targets, contexts, negatives, scale, norm_b, norm_bk):
+        emb = _f32c(emb, "embeddings")
+        targets, contexts = _i64c(targets, "targets"), _i64c(contexts, "contexts")
+        negatives = _i64c(negatives, "negatives")
+        if emb.dim() != 2:
+            raise ValueError("embeddings must be [num_nodes, dim]")
+        if targets.dim() != 1 or contexts.shape != targets.shape:
+            raise ValueError("targets and contexts must be 1-D tensors of equal length")
+        if negatives.dim() != 2 or negatives.size(0) != targets.numel():
+            raise ValueError("negatives must be [batch_size, num_negatives]")
+        coef, stats = skipgram_fwd(emb, targets, contexts, negatives, scale, norm_b, norm_bk)
+        ctx.save_for_backward(emb, targets, contexts, negatives, coef)
+        loss = stats[0].clone()
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_stats):
+        emb, targets, contexts, negatives, coef = ctx.saved_tensors
+        g = grad_loss.to(torch.float32).contiguous()
+        grad_emb = skipgram_bwd(emb, targets, contexts, negatives, coef, g)
+        return grad_emb, None, None, None, None, None, None

@@ -1,0 +1,173 @@
+/*
+ * gsage.h -- C ABI of libgsage.so: the MI355X (gfx950) GraphSAGE training hot path.
+ *
+ * The reference (celestice106/graphsage) has no FFI or operator registry: its hot
+ * path is Python (`GraphSAGE.forward`, `SkipGramLoss.forward[_with_details]`) on
+ * top of torch / torch_geometric ops.  This header is therefore the build's own
+ * boundary; every entry point names the reference code whose
+ * device work it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - sizes and counts are int64_t; CSR indices are int32_t (E, N < 2^31);
+ *   - fp32 everywhere (the reference trains in fp32; parity bar 1e-5 relative);
+ *   - calls are asynchronous launches on `stream` (a hipStream_t passed as void*);
+ *   - the library never allocates or frees device memory (callers bring the
+ *     workspaces; query their sizes with the *_workspace_bytes functions);
+ *   - return value: 0 = ok, negative = gsage_status below.  Errors detected on the
+ *     device (index out of range) are OR-ed into a caller-owned int32 status word.
+ */
+#ifndef GSAGE_H
+#define GSAGE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *gsage_stream_t; /* hipStream_t */
+
+enum gsage_status {
+  GSAGE_OK = 0,
+  GSAGE_ERR_INVALID_ARG = -1,   /* null pointer, negative size, bad enum        */
+  GSAGE_ERR_UNSUPPORTED = -2,   /* shape outside what the kernel handles        */
+  GSAGE_ERR_WORKSPACE = -3,     /* workspace too small                          */
+  GSAGE_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after launch */
+};
+
+/* bits OR-ed into device status words */
+enum gsage_device_flag {
+  GSAGE_FLAG_INDEX_OUT_OF_RANGE = 1
+};
+
+enum gsage_epilogue {
+  GSAGE_EPI_NONE = 0,          /* bare SAGEConv (graphsage.py:138)                */
+  GSAGE_EPI_RELU = 1,          /* F.relu; dropout in eval mode (graphsage.py:134) */
+  GSAGE_EPI_RELU_DROPOUT = 2,  /* F.relu + nn.Dropout(p), train (graphsage.py:134-135) */
+  GSAGE_EPI_L2NORM = 3         /* F.normalize(p=2, dim=1, eps=1e-12) (graphsage.py:142) */
+};
+
+int gsage_version(void);
+const char *gsage_error_string(int status);
+
+/* ------------------------------------------------------------------ K1: CSR build
+ * Replaces the per-call scatter bookkeeping inside PyG's `scatter(reduce='mean')`
+ * (called from graphsage.py:133,138) and the degree loops at
+ * src/walks/negative_sampler.py:76-79 / torch.bincount at src/utils/graph_utils.py:38-39.
+ *
+ *   edge_index : int64 [2,E] row-major; row 0 = source j, row 1 = target i
+ *   rowptr[N+1], col[E]     : in-edges grouped by target, col = sources, edges of one
+ *                             target in ascending edge order (stable) -- bit-exact vs
+ *                             bincount + stable argsort
+ *   rowptr_t[N+1], col_t[E] : the transpose (grouped by source, col_t = targets)
+ *   inv_deg[N]              : 1.0f / max(in_degree, 1)
+ *   long_rows / long_rows_t : ids of rows with more than gsage_long_row_threshold()
+ *                             entries (capacity `long_cap` each); n_long[0] and
+ *                             n_long[1] receive their counts (for the hub-row pass of
+ *                             the aggregation kernels).  May be NULL (then skipped).
+ *   status                  : int32[1], OR-ed with GSAGE_FLAG_INDEX_OUT_OF_RANGE when an
+ *                             index is outside [0,N); such edges are dropped.
+ */
+size_t gsage_csr_workspace_bytes(int64_t E, int64_t N);
+int gsage_long_row_threshold(void);
+int gsage_csr_build(const int64_t *edge_index, int64_t E, int64_t N,
+                    int32_t *rowptr, int32_t *col, int32_t *rowptr_t, int32_t *col_t,
+                    float *inv_deg, int32_t *long_rows, int32_t *long_rows_t,
+                    int64_t long_cap, int32_t *n_long, int32_t *status, void *ws,
+                    size_t ws_bytes, gsage_stream_t stream);
+
+/* ------------------------------------------- K2 / K7: segment gather (mean and sum)
+ * K2 replaces `x.index_select(0, ei[0])` + `scatter_add_` + divide inside PyG's
+ * SAGEConv.propagate (graphsage.py:133,138; direction restated at layers.py:191-195).
+ * K7 replaces the autograd backward of the same (index_add with atomics) by a gather
+ * over the transposed CSR: deterministic, no atomics.
+ *
+ *   out[i,:] = (add_to ? add_to[i,:] : 0) + s_i * sum_{p in [rowptr[i],rowptr[i+1])} w_p * x[col[p],:]
+ *     fwd (mean): s_i = inv_deg[i], w_p = 1                   (edge_weight = NULL)
+ *     bwd       : s_i = 1, w_p = edge_weight[col[p]] or 1     (row_scale   = NULL)
+ *   x, out, add_to: fp32 [N,F] row-major; add_to may alias out.
+ *   long_rows/n_long: hub-row list from gsage_csr_build (NULL => every row by one wave).
+ */
+int gsage_segment_gather(const int32_t *rowptr, const int32_t *col,
+                         const float *row_scale, const float *edge_weight,
+                         const float *x, const float *add_to, int64_t N, int64_t F,
+                         float *out, const int32_t *long_rows, const int32_t *n_long,
+                         gsage_stream_t stream);
+
+/* ------------------------------------------------------------ K3: fused projection
+ * Replaces `F.linear(agg, W_l, b_l) + F.linear(x, W_r)` (PyG SAGEConv.forward) fused
+ * with F.relu / nn.Dropout (graphsage.py:134-135) or F.normalize (graphsage.py:141-142).
+ *
+ *   out[N,Fo] = epi( agg[N,Fi] . W_l[Fo,Fi]^T + b_l[Fo] + x[N,Fi] . W_r[Fo,Fi]^T )
+ *   keep_mask : uint8 [N,Fo] (1 = keep) for RELU_DROPOUT, or NULL to draw the mask in
+ *               the kernel from (seed, element index); kept values are scaled 1/(1-p).
+ *   rnorm     : fp32 [N], written for L2NORM: 1 / max(||row||, 1e-12) (saved for bwd).
+ *   wpack     : fp32 workspace, gsage_project_workspace_bytes(Fi,Fo) bytes.
+ *   fp32-input MFMA (v_mfma_f32_32x32x2_f32) when Fi % 16 == 0 and Fo in {64,128,256};
+ *   a VALU kernel otherwise (e.g. the 7-wide first layer).  `force_generic` != 0
+ *   selects the VALU kernel regardless (tests).
+ */
+size_t gsage_project_workspace_bytes(int64_t Fi, int64_t Fo);
+int gsage_project_fwd(const float *agg, const float *x, const float *w_l,
+                      const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                      int64_t Fo, int epilogue, const uint8_t *keep_mask,
+                      uint64_t seed, float p, float *out, float *rnorm, void *wpack,
+                      int force_generic, gsage_stream_t stream);
+
+/* Backward of K3 (replaces autograd through linear / relu / dropout / normalize).
+ *
+ *   dpre[N,Fo]   = d(loss)/d(pre-epilogue), computed from grad_out, the saved `out`
+ *                  and (L2NORM) `rnorm`; workspace owned by the caller.
+ *   grad_agg[N,Fi] = (dpre . W_l) * (agg_scale ? agg_scale[row] : 1)   (NULL => skipped)
+ *   grad_x[N,Fi]   =  dpre . W_r                                       (NULL => skipped)
+ *   grad_w_l[Fo,Fi] = dpre^T . agg ; grad_w_r[Fo,Fi] = dpre^T . x ; grad_b[Fo] = sum_rows dpre
+ *   ws: gsage_project_bwd_workspace_bytes(N,Fi,Fo) bytes (weight packs + partial slabs,
+ *       reduced in a fixed order => bitwise reproducible).
+ */
+size_t gsage_project_bwd_workspace_bytes(int64_t N, int64_t Fi, int64_t Fo);
+int gsage_project_bwd(const float *grad_out, const float *out, const float *rnorm,
+                      const float *agg, const float *x, const float *w_l,
+                      const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
+                      int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
+                      float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
+                      void *ws, size_t ws_bytes, int force_generic,
+                      gsage_stream_t stream);
+
+/* ---------------------------------------------------------- K4 / K5: skip-gram loss
+ * K4 replaces SkipGramLoss.forward / forward_with_details (src/model/loss.py:97-136,
+ * 161-193): three row gathers, B + B*K dots, x scale, logsigmoid means, and the
+ * monitoring means, in one kernel with no [B,K,D] temporary.
+ *
+ *   emb [N,D] fp32; targets, contexts int64 [B]; negatives int64 [B,K]
+ *   coef [B,1+K] fp32 out: d(loss)/d(raw score): coef[b,0] = -s*sigmoid(-s*pos_b)/B,
+ *                          coef[b,1+k] = s*sigmoid(s*neg_bk)/(B*K)   (saved for K5)
+ *   stats fp32[8] out: total_loss, pos_loss, neg_loss, pos_score_mean, neg_score_mean,
+ *                      pos_prob, neg_prob (loss.py:185-193 order), and [7] = device flag
+ *                      word (as float; non-zero => an index was out of range).
+ *   loss_norm_B / loss_norm_BK: the mean denominators; pass B and B*K for the reference
+ *   semantics, or the GLOBAL batch sizes when this call handles one shard of a batch
+ *   (multi-GPU), so shard losses add up to the global mean.
+ *   ws: gsage_skipgram_workspace_bytes(B) bytes of per-block partials.
+ *
+ * K5 replaces autograd's three index_put(accumulate=True) into a zero [N,D] tensor:
+ *   grad_emb[t_b] += g*(coef_b0*e[c_b] + sum_k coef_bk*e[n_bk]); grad_emb[c_b] += g*coef_b0*e[t_b];
+ *   grad_emb[n_bk] += g*coef_bk*e[t_b], g = *grad_loss (device scalar).
+ *   grad_emb must be zero-filled by the caller (or hold a gradient to accumulate into).
+ */
+size_t gsage_skipgram_workspace_bytes(int64_t B);
+int gsage_skipgram_fwd(const float *emb, int64_t N, int64_t D, const int64_t *targets,
+                       const int64_t *contexts, const int64_t *negatives, int64_t B,
+                       int64_t K, float scale, double loss_norm_B, double loss_norm_BK,
+                       float *coef, float *stats, void *ws, size_t ws_bytes,
+                       gsage_stream_t stream);
+int gsage_skipgram_bwd(const float *emb, int64_t N, int64_t D, const int64_t *targets,
+                       const int64_t *contexts, const int64_t *negatives, int64_t B,
+                       int64_t K, const float *coef, const float *grad_loss,
+                       float *grad_emb, gsage_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSAGE_H */

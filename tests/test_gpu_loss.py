@@ -1,0 +1,119 @@
+"""GPU: K4 / K5 skip-gram loss vs golden vectors produced by the REFERENCE's own loss.py
+(tests/golden/loss_golden.npz) and vs the oracle on larger seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kat
+from oracle import sage_oracle as O
+
+pytestmark = pytest.mark.gpu
+KEYS = ("total_loss", "pos_loss", "neg_loss", "pos_score_mean", "neg_score_mean", "pos_prob", "neg_prob")
+
+
+def _names(golden_dir):
+    z = np.load(os.path.join(golden_dir, "loss_golden.npz"))
+    return z, [str(n) for n in z["names"]]
+
+
+def test_reference_goldens(golden_dir):
+    from graphsage_amd import SkipGramLoss
+    z, names = _names(golden_dir)
+    for name in names:
+        emb = torch.from_numpy(z[f"{name}.emb"]).cuda().requires_grad_()
+        t, c, n = (torch.from_numpy(z[f"{name}.{k}"]).cuda() for k in ("targets", "contexts", "negatives"))
+        fn = SkipGramLoss(scale_factor=float(z[f"{name}.scale"]))
+        loss, det = fn.forward_with_details(emb, t, c, n)
+        assert loss.dim() == 0
+        assert loss.item() == pytest.approx(float(z[f"{name}.loss"]), rel=1e-5), name
+        for i, k in enumerate(KEYS):
+            assert det[k] == pytest.approx(z[f"{name}.details"][i], rel=1e-5, abs=1e-7), (name, k)
+        loss.backward()
+        ref = torch.from_numpy(z[f"{name}.grad"])
+        assert torch.allclose(emb.grad.cpu(), ref, rtol=1e-5, atol=1e-7), name
+        assert fn(emb.detach(), t, c, n).item() == pytest.approx(float(z[f"{name}.loss"]), rel=1e-5)
+
+
+def test_kat5_by_hand():
+    from graphsage_amd import SkipGramLoss
+    k = kat.KAT5
+    loss, det = SkipGramLoss(k["scale"]).forward_with_details(
+        torch.tensor(k["emb"]).cuda(), torch.tensor(k["targets"]).cuda(),
+        torch.tensor(k["contexts"]).cuda(), torch.tensor(k["negatives"]).cuda())
+    assert loss.item() == pytest.approx(k["loss"], rel=1e-6)
+    assert det["pos_prob"] == pytest.approx(k["pos_prob"], rel=1e-6)
+    assert det["neg_prob"] == pytest.approx(k["neg_prob"], rel=1e-6)
+
+
+@pytest.mark.parametrize("n,d,b,k", [(100_000, 64, 131072, 5), (5000, 128, 1024, 5), (3000, 256, 513, 9),
+                                     (2000, 48, 777, 2), (2000, 6, 100, 5), (1000, 320, 64, 5)])
+def test_against_oracle(n, d, b, k):
+    from graphsage_amd import SkipGramLoss
+    g = torch.Generator().manual_seed(n + d)
+    emb = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).requires_grad_()
+    t = torch.randint(0, n, (b,), generator=g)
+    c = torch.randint(0, n, (b,), generator=g)
+    neg = torch.randint(0, n, (b, k), generator=g)
+    ref, rdet = O.skipgram_loss_with_details(emb, t, c, neg, 5.0)
+    ref.backward()
+    e2 = emb.detach().cuda().requires_grad_()
+    loss, det = SkipGramLoss(5.0).forward_with_details(e2, t.cuda(), c.cuda(), neg.cuda())
+    (loss * 3.0).backward()                                   # upstream gradient != 1
+    assert loss.item() == pytest.approx(ref.item(), rel=1e-5)
+    for key in KEYS:
+        assert det[key] == pytest.approx(rdet[key], rel=1e-5, abs=1e-7)
+    assert torch.allclose(e2.grad.cpu() / 3.0, emb.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_sharded_losses_add_up_to_global_mean():
+    from graphsage_amd import SkipGramLoss, shard_bounds
+    g = torch.Generator().manual_seed(3)
+    n, d, b, k = 4000, 64, 1001, 5
+    emb = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).cuda()
+    t, c = torch.randint(0, n, (b,), generator=g).cuda(), torch.randint(0, n, (b,), generator=g).cuda()
+    neg = torch.randint(0, n, (b, k), generator=g).cuda()
+    fn = SkipGramLoss()
+    full, stats = fn.forward_stats(emb, t, c, neg)
+    parts = torch.zeros(8, device="cuda")
+    for r in range(3):
+        lo, hi = shard_bounds(b, r, 3)
+        _, s = fn.forward_stats(emb, t[lo:hi], c[lo:hi], neg[lo:hi], global_batch=b)
+        parts += s
+    assert torch.allclose(parts[:7], stats[:7], rtol=1e-5, atol=1e-7)
+
+
+def test_loss_value_bitwise_reproducible():
+    from graphsage_amd import SkipGramLoss
+    g = torch.Generator().manual_seed(4)
+    emb = torch.randn(10000, 64, generator=g).cuda()
+    t, c = torch.randint(0, 10000, (50000,), generator=g).cuda(), torch.randint(0, 10000, (50000,), generator=g).cuda()
+    neg = torch.randint(0, 10000, (50000, 5), generator=g).cuda()
+    fn = SkipGramLoss()
+    _, s1 = fn.forward_stats(emb, t, c, neg)
+    _, s2 = fn.forward_stats(emb, t, c, neg)
+    assert torch.equal(s1, s2)
+
+
+def test_out_of_range_pair_index_raises():
+    from graphsage_amd import SkipGramLoss
+    emb = torch.randn(10, 64).cuda()
+    t = torch.tensor([1, 2]).cuda()
+    c = torch.tensor([3, 10]).cuda()           # 10 is out of range
+    neg = torch.tensor([[1, 2], [3, 4]]).cuda()
+    with pytest.raises(IndexError):
+        SkipGramLoss().forward_with_details(emb, t, c, neg)
+
+
+def test_rejects_wrong_inputs():
+    from graphsage_amd import SkipGramLoss
+    emb = torch.randn(10, 64).cuda()
+    t = torch.tensor([1, 2]).cuda()
+    neg = torch.tensor([[1, 2], [3, 4]]).cuda()
+    with pytest.raises(ValueError):
+        SkipGramLoss()(emb, t, t[:1], neg)
+    with pytest.raises(ValueError):
+        SkipGramLoss()(emb, t.int(), t, neg)
+    with pytest.raises(ValueError):
+        SkipGramLoss()(emb.cpu(), t.cpu(), t.cpu(), neg.cpu())     # no CPU path

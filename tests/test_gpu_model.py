@@ -1,0 +1,181 @@
+"""GPU: the drop-in GraphSAGE module and the training step vs the oracle, with the
+invariants the reference's own tests assert (tests/test_model.py:45-99, 126-156)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sage_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def _pair(cfg, seed=0):
+    """(product model on GPU, oracle model on CPU) with identical weights."""
+    from graphsage_amd import GraphSAGE
+    torch.manual_seed(seed)
+    ref = O.OracleGraphSAGE(**cfg)
+    m = GraphSAGE(**cfg)
+    m.load_state_dict(ref.state_dict(), strict=True)      # PyG-compatible keys both sides
+    return m.cuda(), ref
+
+
+CFGS = [
+    dict(in_channels=7, hidden_channels=64, out_channels=64, num_layers=2, dropout=0.3),   # default
+    dict(in_channels=7, hidden_channels=128, out_channels=128, num_layers=2, dropout=0.3),  # C3
+    dict(in_channels=7, hidden_channels=256, out_channels=256, num_layers=3, dropout=0.0),  # C5
+    dict(in_channels=7, hidden_channels=32, out_channels=32, num_layers=2, dropout=0.3),   # ref integration test
+    dict(in_channels=7, hidden_channels=64, out_channels=48, num_layers=1, dropout=0.3),   # num_layers==1 quirk
+    dict(in_channels=7, hidden_channels=64, out_channels=64, num_layers=2, dropout=0.3, normalize_output=False),
+]
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_eval_forward_matches_oracle(cfg):
+    m, ref = _pair(cfg)
+    n = 700
+    x = torch.randn(n, 7)
+    ei = torch.randint(0, n, (2, 5000))
+    m.eval(), ref.eval()
+    with torch.no_grad():
+        got = m(x.cuda(), ei.cuda())
+        want = ref(x, ei)
+    assert got.shape == want.shape
+    assert torch.allclose(got.cpu(), want, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("cfg", CFGS[:4])
+def test_train_forward_backward_with_injected_masks(cfg):
+    m, ref = _pair(cfg, seed=1)
+    n = 600
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 7, generator=g)
+    ei = torch.randint(0, n, (2, 6000), generator=g)
+    p = cfg["dropout"]
+    nh = cfg["num_layers"] - 1
+    keep = [(torch.rand(n, cfg["hidden_channels"], generator=g) >= p).to(torch.uint8) for _ in range(nh)]
+    gout = torch.randn(n, cfg["out_channels"], generator=g)
+    m.train(), ref.train()
+    want = ref(x, ei, keep_masks=[k.float() for k in keep])
+    want.backward(gout)
+    got = m(x.cuda(), ei.cuda(), keep_masks=[k.cuda() for k in keep])
+    got.backward(gout.cuda())
+    assert torch.allclose(got.detach().cpu(), want.detach(), rtol=RTOL, atol=ATOL)
+    for (name, pg), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        assert pg.grad is not None, name
+        scale = pr.grad.abs().max().item() + 1e-12
+        assert torch.allclose(pg.grad.cpu(), pr.grad, rtol=2e-5, atol=2e-5 * scale), name
+
+
+def test_input_gradient_when_features_require_grad():
+    cfg = CFGS[0]
+    m, ref = _pair(cfg, seed=2)
+    m.eval(), ref.eval()
+    n = 300
+    x = torch.randn(n, 7)
+    ei = torch.randint(0, n, (2, 2500))
+    xr = x.clone().requires_grad_()
+    ref(xr, ei).pow(2).sum().backward()      # sum of squared unit rows is constant -> use a weight
+    xr.grad = None
+    w = torch.randn(n, 64)
+    (ref(xr, ei) * w).sum().backward()
+    xg = x.cuda().requires_grad_()
+    (m(xg, ei.cuda()) * w.cuda()).sum().backward()
+    assert torch.allclose(xg.grad.cpu(), xr.grad, rtol=2e-5, atol=1e-6)
+
+
+def test_reference_test_invariants():
+    """tests/test_model.py:23-99 of the reference, on the drop-in class."""
+    from graphsage_amd import GraphSAGE
+    torch.manual_seed(0)
+    model = GraphSAGE(in_channels=7, hidden_channels=64, out_channels=64, num_layers=2, dropout=0.3).cuda()
+    features = torch.randn(100, 7).cuda()
+    edge_index = torch.randint(0, 100, (2, 500)).cuda()
+    model.eval()
+    out = model(features, edge_index)
+    assert out.shape == (100, 64)
+    assert torch.allclose(out.norm(p=2, dim=1), torch.ones(100, device="cuda"), atol=1e-5)
+    model.train()
+    model(features, edge_index).sum().backward()
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+    assert 0 < model.count_parameters() < 100000 and model.count_parameters() == 9216
+    assert model.get_embedding_dim() == 64 and model.in_channels == 7
+    with pytest.raises(ValueError):
+        GraphSAGE(aggregator="lstm")
+
+
+def test_train_mode_dropout_is_seeded_and_scaled():
+    from graphsage_amd import GraphSAGE
+    torch.manual_seed(3)
+    model = GraphSAGE(dropout=0.5, normalize_output=False).cuda().train()
+    x = torch.randn(2000, 7).cuda()
+    ei = torch.randint(0, 2000, (2, 20000)).cuda()
+    torch.manual_seed(7)
+    a = model(x, ei)
+    torch.manual_seed(7)
+    b = model(x, ei)
+    c = model(x, ei)
+    assert torch.equal(a, b) and not torch.equal(a, c)        # reproducible under manual_seed
+    model.eval()
+    e = model(x, ei)
+    assert not torch.allclose(a, e)
+
+
+def test_c1_fixture_embeddings_match_snapshot(golden_dir):
+    from graphsage_amd import GraphSAGE
+    z = np.load(os.path.join(golden_dir, "c1_graph.npz"))
+    s = np.load(os.path.join(golden_dir, "oracle_c1_snapshot.npz"))
+    torch.manual_seed(0)
+    ref = O.OracleGraphSAGE(7, 64, 64, 2, 0.3)
+    m = GraphSAGE(7, 64, 64, 2, 0.3)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda().eval()
+    emb = m(torch.from_numpy(z["features"]).cuda(), torch.from_numpy(z["edge_index"]).cuda())
+    assert torch.allclose(emb.detach().cpu(), torch.from_numpy(s["embeddings"]), rtol=RTOL, atol=ATOL)
+
+
+def test_training_steps_track_the_oracle():
+    """Five full steps (trainer.py:213-240): zero_grad, fwd, loss, bwd, clip, Adam."""
+    from graphsage_amd import GraphSAGE, TrainStep
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    n, b, k = 3000, 1024, 5
+    ei = powerlaw_graph(n, 10, seed=42)
+    x = memory_features(n, seed=42)
+    cfg = dict(in_channels=7, hidden_channels=64, out_channels=64, num_layers=2, dropout=0.0)
+    m, ref = _pair(cfg, seed=4)
+    ts = TrainStep(m, x.cuda(), ei.cuda())
+    opt = O.make_adam(ref)
+    ref.train()
+    for step in range(5):
+        t, c, neg = cooccurrence_batch(ei, n, b, k, seed=100 + step)
+        rl, rdet = O.train_step(ref, opt, x, ei, t, c, neg)
+        det = ts.step_with_details(t.cuda(), c.cuda(), neg.cuda())
+        assert det["total_loss"] == pytest.approx(rdet["total_loss"], rel=2e-5), step
+        assert det["pos_prob"] == pytest.approx(rdet["pos_prob"], rel=2e-5), step
+    for (name, pg), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(pg.detach().cpu(), pr.detach(), rtol=1e-4, atol=2e-5), name
+    emb = ts.get_embeddings()
+    ref.eval()
+    assert torch.allclose(emb.cpu(), ref(x, ei).detach(), rtol=1e-4, atol=1e-5)
+
+
+def test_full_size_c2_properties():
+    """C2 (100k nodes, ~2M edges): unit norms, no NaN/Inf, determinism of the forward, and
+    agreement with the oracle run on the same inputs (the oracle finishes in ~1 s here)."""
+    from graphsage_amd.synth import memory_features, powerlaw_graph
+    n = 100_000
+    ei = powerlaw_graph(n, 20, seed=42, device="cuda")
+    x = memory_features(n, seed=42, device="cuda")
+    m, ref = _pair(CFGS[0], seed=0)
+    m.eval(), ref.eval()
+    with torch.no_grad():
+        e1 = m(x, ei)
+        e2 = m(x, ei)
+        want = ref(x.cpu(), ei.cpu())
+    assert torch.equal(e1, e2)
+    assert torch.isfinite(e1).all()
+    assert torch.allclose(e1.norm(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
+    assert torch.allclose(e1.cpu(), want, rtol=RTOL, atol=ATOL)

@@ -1,0 +1,122 @@
+"""GPU: K3 fused projection forward/backward vs plain torch fp32 (F.linear / relu /
+dropout-with-given-mask / F.normalize) on the CPU.  MFMA and VALU paths both."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from graphsage_amd import _lib
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-5, 2e-6
+
+EPIS = [_lib.EPI_NONE, _lib.EPI_RELU, _lib.EPI_RELU_DROPOUT, _lib.EPI_L2NORM]
+
+
+def _ref(agg, x, wl, bl, wr, epi, keep, p):
+    pre = F.linear(agg, wl, bl) + F.linear(x, wr)
+    if epi == _lib.EPI_NONE:
+        return pre
+    if epi == _lib.EPI_RELU:
+        return F.relu(pre)
+    if epi == _lib.EPI_RELU_DROPOUT:
+        return F.relu(pre) * keep.to(torch.float32) / (1.0 - p)
+    return F.normalize(pre, p=2, dim=1)
+
+
+def _case(n, fi, fo, seed):
+    g = torch.Generator().manual_seed(seed)
+    agg = torch.randn(n, fi, generator=g)
+    x = torch.randn(n, fi, generator=g)
+    wl = torch.randn(fo, fi, generator=g) / fi ** 0.5
+    wr = torch.randn(fo, fi, generator=g) / fi ** 0.5
+    bl = torch.randn(fo, generator=g)
+    keep = (torch.rand(n, fo, generator=g) >= 0.3).to(torch.uint8)
+    gout = torch.randn(n, fo, generator=g)
+    return agg, x, wl, bl, wr, keep, gout
+
+
+SHAPES = [(7, 64), (64, 64), (64, 128), (128, 128), (128, 64), (256, 256), (7, 32), (32, 32),
+          (5, 3), (64, 96), (20, 64), (7, 100)]
+
+
+@pytest.mark.parametrize("epi", EPIS)
+@pytest.mark.parametrize("fi,fo", SHAPES)
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_forward_backward(fi, fo, epi, force_generic):
+    from graphsage_amd.ops import project_bwd, project_fwd
+    if force_generic and (fi, fo) not in [(64, 64), (128, 64), (7, 64)]:
+        pytest.skip("generic path already selected by shape")
+    n, p = 333, 0.3          # not a multiple of the 64-row tile
+    agg, x, wl, bl, wr, keep, gout = _case(n, fi, fo, fi * 1000 + fo)
+    leaves = [t.clone().requires_grad_() for t in (agg, x, wl, bl, wr)]
+    ref = _ref(*leaves, epi, keep, p)
+    ref.backward(gout)
+    d = [t.cuda() for t in (agg, x, wl, bl, wr)]
+    out, rnorm = project_fwd(*d, epilogue=epi, keep_mask=keep.cuda() if epi == _lib.EPI_RELU_DROPOUT else None,
+                             p=p if epi == _lib.EPI_RELU_DROPOUT else 0.0, force_generic=force_generic)
+    assert torch.allclose(out.cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+    scale = torch.rand(n).cuda() + 0.5
+    ga, gx, gwl, gb, gwr = project_bwd(gout.cuda(), out, rnorm, d[0], d[1], d[2], d[4], scale, epi,
+                                       p if epi == _lib.EPI_RELU_DROPOUT else 0.0, True,
+                                       force_generic=force_generic)
+    tol = dict(rtol=2e-5, atol=2e-5)
+    assert torch.allclose((ga / scale[:, None]).cpu(), leaves[0].grad, **tol)
+    assert torch.allclose(gx.cpu(), leaves[1].grad, **tol)
+    assert torch.allclose(gwl.cpu(), leaves[2].grad, rtol=2e-5, atol=1e-4)
+    assert torch.allclose(gb.cpu(), leaves[3].grad, rtol=2e-5, atol=1e-4)
+    assert torch.allclose(gwr.cpu(), leaves[4].grad, rtol=2e-5, atol=1e-4)
+
+
+def test_mfma_identity_asymmetric():
+    """A = I against an asymmetric B: catches a transposed C write or a swapped operand map."""
+    from graphsage_amd.ops import project_fwd
+    n = 64
+    agg = torch.eye(64)[:n].contiguous()
+    x = torch.zeros(n, 64)
+    wl = (torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64) % 97) - 40.0   # wl[j,k] != wl[k,j]
+    wr = torch.zeros(64, 64)
+    bl = torch.zeros(64)
+    out, _ = project_fwd(agg.cuda(), x.cuda(), wl.cuda(), bl.cuda(), wr.cuda())
+    assert torch.equal(out.cpu(), wl.t().contiguous())     # out[i,j] = wl[j,i], exact integers
+
+
+def test_l2norm_zero_row_and_rnorm():
+    from graphsage_amd.ops import project_bwd, project_fwd
+    n, f = 70, 64
+    agg = torch.zeros(n, f)
+    x = torch.zeros(n, f)
+    x[1:] = torch.randn(n - 1, f)
+    wl, wr, bl = torch.randn(f, f), torch.randn(f, f), torch.zeros(f)   # row 0 -> pre = 0
+    leaves = [t.clone().requires_grad_() for t in (agg, x, wl, bl, wr)]
+    ref = F.normalize(F.linear(leaves[0], leaves[2], leaves[3]) + F.linear(leaves[1], leaves[4]), dim=1)
+    out, rnorm = project_fwd(agg.cuda(), x.cuda(), wl.cuda(), bl.cuda(), wr.cuda(), epilogue=_lib.EPI_L2NORM)
+    assert torch.count_nonzero(out[0]).item() == 0          # 0 / max(0, 1e-12) = 0 (KAT-4)
+    assert torch.allclose(out.cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+    assert torch.allclose(out[1:].norm(dim=1).cpu(), torch.ones(n - 1), atol=1e-5)
+
+
+def test_inkernel_dropout_matches_host_mirror():
+    from graphsage_amd.ops import project_fwd
+    from graphsage_amd.rng import dropout_keep_mask
+    p, seed = 0.3, 0x1234_5678_9ABC_DEF1
+    for (n, fi, fo, fg) in [(500, 7, 64, False), (200, 64, 64, False), (200, 64, 128, False), (100, 20, 48, False)]:
+        agg, x, wl, bl, wr, _, _ = _case(n, fi, fo, 5)
+        d = [t.cuda() for t in (agg, x, wl, bl, wr)]
+        out, _ = project_fwd(*d, epilogue=_lib.EPI_RELU_DROPOUT, seed=seed, p=p, force_generic=fg)
+        keep = torch.from_numpy(dropout_keep_mask(seed, n, fo, p))
+        ref = _ref(agg, x, wl, bl, wr, _lib.EPI_RELU_DROPOUT, keep, p)
+        assert torch.allclose(out.cpu(), ref, rtol=RTOL, atol=ATOL)
+        frac = keep.float().mean().item()
+        assert abs(frac - (1 - p)) < 0.02
+
+
+def test_weight_grads_bitwise_reproducible():
+    from graphsage_amd.ops import project_bwd, project_fwd
+    n, fi, fo = 5000, 64, 64
+    agg, x, wl, bl, wr, keep, gout = _case(n, fi, fo, 9)
+    d = [t.cuda() for t in (agg, x, wl, bl, wr)]
+    out, rn = project_fwd(*d, epilogue=_lib.EPI_L2NORM)
+    r1 = project_bwd(gout.cuda(), out, rn, d[0], d[1], d[2], d[4], None, _lib.EPI_L2NORM, 0.0, True)
+    r2 = project_bwd(gout.cuda(), out, rn, d[0], d[1], d[2], d[4], None, _lib.EPI_L2NORM, 0.0, True)
+    for a, b in zip(r1, r2):
+        assert torch.equal(a, b)
