@@ -6,6 +6,7 @@ K1 kernels (``gsage_csr_build``) and reused by every layer, forward and backward
 """
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -79,26 +80,28 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int, check: bool = True) -> G
 
 
 class GraphCache:
-    """Keeps the CSR of the graphs recently seen, keyed on the identity of the
-    ``edge_index`` tensor (pointer, shape, in-place version counter, device)."""
+    """Keeps the CSR of the graphs recently seen, keyed on the identity of the ``edge_index``
+    tensor OBJECT (held weakly) and its in-place version counter.  A device pointer alone is
+    not an identity: the caching allocator hands the same address to the next graph."""
 
     def __init__(self, capacity: int = 4):
         self.capacity = capacity
-        self._store: Dict[Tuple, GraphCSR] = {}
-
-    @staticmethod
-    def _key(edge_index: torch.Tensor, num_nodes: int) -> Tuple:
-        return (edge_index.data_ptr(), tuple(edge_index.shape), tuple(edge_index.stride()),
-                edge_index._version, str(edge_index.device), int(num_nodes))
+        self._store: Dict[int, Tuple] = {}
 
     def get(self, edge_index: torch.Tensor, num_nodes: int) -> GraphCSR:
-        k = self._key(edge_index, num_nodes)
-        g = self._store.get(k)
-        if g is None:
-            g = build_csr(edge_index, num_nodes)
-            if len(self._store) >= self.capacity:
-                self._store.pop(next(iter(self._store)))
-            self._store[k] = g
+        k = id(edge_index)
+        ent = self._store.get(k)
+        if ent is not None:
+            ref, version, n, g = ent
+            if ref() is edge_index and version == edge_index._version and n == int(num_nodes):
+                return g
+            del self._store[k]
+        for dead in [kk for kk, e in self._store.items() if e[0]() is None]:
+            del self._store[dead]
+        g = build_csr(edge_index, num_nodes)
+        if len(self._store) >= self.capacity:
+            self._store.pop(next(iter(self._store)))
+        self._store[k] = (weakref.ref(edge_index), edge_index._version, int(num_nodes), g)
         return g
 
     def clear(self) -> None:

@@ -6,6 +6,8 @@ import torch
 from oracle import kat
 from oracle import sage_oracle as O
 
+from util import assert_close
+
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-5, 1e-6   # north_star: 1e-5 relative (fp32)
 
@@ -33,7 +35,7 @@ def test_forward_matches_oracle(f):
     x = torch.randn(n, f, generator=torch.Generator().manual_seed(f + 1))
     ref = O.mean_aggregate(x, ei)
     got = aggregate_mean(build_csr(ei.cuda(), n), x.cuda())
-    assert torch.allclose(got.cpu(), ref, rtol=RTOL, atol=ATOL)
+    assert_close(got.cpu(), ref)
 
 
 @pytest.mark.parametrize("f", [7, 64, 128])
@@ -47,12 +49,12 @@ def test_backward_matches_autograd_of_oracle(f):
     O.mean_aggregate(x, ei).backward(gout)
     g = build_csr(ei.cuda(), n)
     got = aggregate_mean_bwd(g, gout.cuda())
-    assert torch.allclose(got.cpu(), x.grad, rtol=RTOL, atol=ATOL)
+    assert_close(got.cpu(), x.grad)
     # prescaled form + accumulate into an existing gradient
     base = torch.randn(n, f)
     got2 = aggregate_mean_bwd(g, (gout.cuda() * g.inv_deg[:, None]), prescaled=True,
                               add_to=base.cuda().clone())
-    assert torch.allclose(got2.cpu(), x.grad + base, rtol=RTOL, atol=ATOL)
+    assert_close(got2.cpu(), x.grad + base)
 
 
 @pytest.mark.parametrize("f", [64, 7, 256])
@@ -69,12 +71,12 @@ def test_hub_rows_and_isolated_rows(f):
     g = build_csr(ei.cuda(), n)
     assert g.n_long[0].item() >= 1
     got = aggregate_mean(g, x.detach().cuda())
-    assert torch.allclose(got.cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+    assert_close(got.cpu(), ref.detach())
     assert torch.count_nonzero(got[-100:]).item() == 0
     gout = torch.randn(n, f)
     ref.backward(gout)
     gb = aggregate_mean_bwd(g, gout.cuda())
-    assert torch.allclose(gb.cpu(), x.grad, rtol=RTOL, atol=2e-6)
+    assert_close(gb.cpu(), x.grad)
 
 
 def test_bitwise_reproducible_and_linear_at_c2_size():
@@ -90,9 +92,9 @@ def test_bitwise_reproducible_and_linear_at_c2_size():
     a1, a2 = aggregate_mean(g, x), aggregate_mean(g, x)
     assert torch.equal(a1, a2)
     lin = aggregate_mean(g, 2.0 * x + y)
-    assert torch.allclose(lin, 2.0 * a1 + aggregate_mean(g, y), rtol=1e-4, atol=1e-5)
+    assert_close(lin, 2.0 * a1 + aggregate_mean(g, y), rtol=1e-4, floor=1e-5)
     ones = aggregate_mean(g, torch.ones(n, 64, device="cuda"))
     has_in = (g.in_degree() > 0).to(torch.float32)[:, None].expand(-1, 64)
-    assert torch.allclose(ones, has_in, rtol=1e-6, atol=1e-6)   # mean of ones is 1 (0 if isolated)
+    assert_close(ones, has_in)   # mean of ones is 1 (0 if isolated)
     ref = O.mean_aggregate(x.cpu(), ei.cpu())
-    assert torch.allclose(a1.cpu(), ref, rtol=RTOL, atol=ATOL)
+    assert_close(a1.cpu(), ref)

@@ -9,6 +9,8 @@ import torch
 from oracle import kat
 from oracle import sage_oracle as O
 
+from util import assert_close
+
 pytestmark = pytest.mark.gpu
 KEYS = ("total_loss", "pos_loss", "neg_loss", "pos_score_mean", "neg_score_mean", "pos_prob", "neg_prob")
 
@@ -32,7 +34,7 @@ def test_reference_goldens(golden_dir):
             assert det[k] == pytest.approx(z[f"{name}.details"][i], rel=1e-5, abs=1e-7), (name, k)
         loss.backward()
         ref = torch.from_numpy(z[f"{name}.grad"])
-        assert torch.allclose(emb.grad.cpu(), ref, rtol=1e-5, atol=1e-7), name
+        assert_close(emb.grad.cpu(), ref, what=str(name))
         assert fn(emb.detach(), t, c, n).item() == pytest.approx(float(z[f"{name}.loss"]), rel=1e-5)
 
 
@@ -64,7 +66,7 @@ def test_against_oracle(n, d, b, k):
     assert loss.item() == pytest.approx(ref.item(), rel=1e-5)
     for key in KEYS:
         assert det[key] == pytest.approx(rdet[key], rel=1e-5, abs=1e-7)
-    assert torch.allclose(e2.grad.cpu() / 3.0, emb.grad, rtol=1e-5, atol=1e-7)
+    assert_close(e2.grad.cpu() / 3.0, emb.grad)
 
 
 def test_sharded_losses_add_up_to_global_mean():
@@ -81,7 +83,7 @@ def test_sharded_losses_add_up_to_global_mean():
         lo, hi = shard_bounds(b, r, 3)
         _, s = fn.forward_stats(emb, t[lo:hi], c[lo:hi], neg[lo:hi], global_batch=b)
         parts += s
-    assert torch.allclose(parts[:7], stats[:7], rtol=1e-5, atol=1e-7)
+    assert_close(parts[:7], stats[:7])
 
 
 def test_loss_value_bitwise_reproducible():

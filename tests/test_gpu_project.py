@@ -6,6 +6,8 @@ import torch.nn.functional as F
 
 from graphsage_amd import _lib
 
+from util import assert_close
+
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-5, 2e-6
 
@@ -54,17 +56,16 @@ def test_forward_backward(fi, fo, epi, force_generic):
     d = [t.cuda() for t in (agg, x, wl, bl, wr)]
     out, rnorm = project_fwd(*d, epilogue=epi, keep_mask=keep.cuda() if epi == _lib.EPI_RELU_DROPOUT else None,
                              p=p if epi == _lib.EPI_RELU_DROPOUT else 0.0, force_generic=force_generic)
-    assert torch.allclose(out.cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+    assert_close(out.cpu(), ref.detach())
     scale = torch.rand(n).cuda() + 0.5
     ga, gx, gwl, gb, gwr = project_bwd(gout.cuda(), out, rnorm, d[0], d[1], d[2], d[4], scale, epi,
                                        p if epi == _lib.EPI_RELU_DROPOUT else 0.0, True,
                                        force_generic=force_generic)
-    tol = dict(rtol=2e-5, atol=2e-5)
-    assert torch.allclose((ga / scale[:, None]).cpu(), leaves[0].grad, **tol)
-    assert torch.allclose(gx.cpu(), leaves[1].grad, **tol)
-    assert torch.allclose(gwl.cpu(), leaves[2].grad, rtol=2e-5, atol=1e-4)
-    assert torch.allclose(gb.cpu(), leaves[3].grad, rtol=2e-5, atol=1e-4)
-    assert torch.allclose(gwr.cpu(), leaves[4].grad, rtol=2e-5, atol=1e-4)
+    assert_close((ga / scale[:, None]).cpu(), leaves[0].grad)
+    assert_close(gx.cpu(), leaves[1].grad)
+    assert_close(gwl.cpu(), leaves[2].grad)
+    assert_close(gb.cpu(), leaves[3].grad)
+    assert_close(gwr.cpu(), leaves[4].grad)
 
 
 def test_mfma_identity_asymmetric():
@@ -91,7 +92,7 @@ def test_l2norm_zero_row_and_rnorm():
     ref = F.normalize(F.linear(leaves[0], leaves[2], leaves[3]) + F.linear(leaves[1], leaves[4]), dim=1)
     out, rnorm = project_fwd(agg.cuda(), x.cuda(), wl.cuda(), bl.cuda(), wr.cuda(), epilogue=_lib.EPI_L2NORM)
     assert torch.count_nonzero(out[0]).item() == 0          # 0 / max(0, 1e-12) = 0 (KAT-4)
-    assert torch.allclose(out.cpu(), ref.detach(), rtol=RTOL, atol=ATOL)
+    assert_close(out.cpu(), ref.detach())
     assert torch.allclose(out[1:].norm(dim=1).cpu(), torch.ones(n - 1), atol=1e-5)
 
 
@@ -105,7 +106,7 @@ def test_inkernel_dropout_matches_host_mirror():
         out, _ = project_fwd(*d, epilogue=_lib.EPI_RELU_DROPOUT, seed=seed, p=p, force_generic=fg)
         keep = torch.from_numpy(dropout_keep_mask(seed, n, fo, p))
         ref = _ref(agg, x, wl, bl, wr, _lib.EPI_RELU_DROPOUT, keep, p)
-        assert torch.allclose(out.cpu(), ref, rtol=RTOL, atol=ATOL)
+        assert_close(out.cpu(), ref)
         frac = keep.float().mean().item()
         assert abs(frac - (1 - p)) < 0.02
 
