@@ -30,6 +30,35 @@ def _i64c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+# ---------------------------------------------------------------- optional kernel timing
+class KernelTimer:
+    """Brackets selected C-ABI calls with HIP events on the stream they are launched on
+    (torch's current stream), for bench.py's live per-kernel durations."""
+
+    def __init__(self):
+        self.records = {}
+        self.enabled = True
+
+    def bracket(self, name):
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(name, []).append((start, end))
+        return start, end
+
+    def summary(self):
+        """name -> (launches, mean milliseconds); call after a device synchronize."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v))
+                for k, v in self.records.items() if v}
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(timer: Optional[KernelTimer]) -> None:
+    global _timer
+    _timer = timer
+
+
 # ----------------------------------------------------------------------------- raw ops
 def segment_gather(rowptr, col, x, row_scale=None, edge_weight=None, add_to=None, out=None,
                    long_rows=None, n_long=None) -> torch.Tensor:
@@ -40,10 +69,15 @@ def segment_gather(rowptr, col, x, row_scale=None, edge_weight=None, add_to=None
     if out is None:
         out = torch.empty_like(x)
     with torch.cuda.device(x.device):
+        ev = _timer.bracket(f"segment_gather_F{F}") if _timer is not None and _timer.enabled else None
+        if ev:
+            ev[0].record()
         rc = lib.gsage_segment_gather(rowptr.data_ptr(), col.data_ptr(), _lib.ptr(row_scale),
                                       _lib.ptr(edge_weight), x.data_ptr(), _lib.ptr(add_to),
                                       N, F, out.data_ptr(), _lib.ptr(long_rows),
                                       _lib.ptr(n_long), _lib.stream_handle())
+        if ev:
+            ev[1].record()
     _lib.check(rc, "gsage_segment_gather")
     return out
 
