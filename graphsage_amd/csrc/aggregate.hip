@@ -249,6 +249,8 @@ extern "C" int gsage_segment_gather(const int32_t *rowptr, const int32_t *col,
   bool aligned = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)add_to) & 15) == 0;
   if (aligned) {
     switch (F) {
+      case 4:   return launch_vec<1>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
+      case 8:   return launch_vec<2>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
       case 16:  return launch_vec<4>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
       case 32:  return launch_vec<8>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
       case 64:  return launch_vec<16>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);

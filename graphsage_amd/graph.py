@@ -86,7 +86,7 @@ class GraphCache:
 
     def __init__(self, capacity: int = 4):
         self.capacity = capacity
-        self._store: Dict[int, Tuple] = {}
+        self._store: Dict[object, Tuple] = {}
 
     def get(self, edge_index: torch.Tensor, num_nodes: int) -> GraphCSR:
         k = id(edge_index)
@@ -103,6 +103,23 @@ class GraphCache:
             self._store.pop(next(iter(self._store)))
         self._store[k] = (weakref.ref(edge_index), edge_index._version, int(num_nodes), g)
         return g
+
+    def padded(self, x: torch.Tensor, width: int) -> torch.Tensor:
+        """``x`` zero-padded to ``width`` columns.  Cached per tensor object + version when x
+        needs no gradient (node features are constant across training steps)."""
+        pad = width - x.size(1)
+        if x.requires_grad:
+            return torch.nn.functional.pad(x, (0, pad))
+        k = ("pad", id(x), width)
+        ent = self._store.get(k)
+        if ent is not None:
+            ref, version, xp = ent
+            if ref() is x and version == x._version:
+                return xp
+            del self._store[k]
+        xp = torch.nn.functional.pad(x, (0, pad)).contiguous()
+        self._store[k] = (weakref.ref(x), x._version, xp)
+        return xp
 
     def clear(self) -> None:
         self._store.clear()

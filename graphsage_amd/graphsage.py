@@ -13,10 +13,23 @@ from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib
 from .graph import GraphCSR, default_cache
 from .ops import SAGELayerFunction
+
+
+_VEC_WIDTHS = (4, 8, 16, 32, 64, 128, 256)
+
+
+def vector_width(f: int) -> int:
+    """Feature width the vectorised gather kernels take for an ``f``-column input: the next
+    of 4,8,...,256 if that costs at most a third more columns, else ``f`` itself."""
+    for w in _VEC_WIDTHS:
+        if f <= w:
+            return w if w * 3 <= f * 4 else f
+    return f
 
 
 class SAGEConv(nn.Module):
@@ -44,8 +57,16 @@ class SAGEConv(nn.Module):
     def run(self, x: torch.Tensor, graph: GraphCSR, epilogue: int = _lib.EPI_NONE, p: float = 0.0,
             seed: int = 0, keep_mask: Optional[torch.Tensor] = None,
             force_generic: bool = False) -> torch.Tensor:
-        return SAGELayerFunction.apply(x, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight,
-                                       graph, epilogue, p, seed, keep_mask, force_generic)
+        w_l, w_r = self.lin_l.weight, self.lin_r.weight
+        width = vector_width(x.size(1))
+        if width != x.size(1) and not force_generic:
+            # e.g. the 7 memory features -> 8 columns: 32-byte rows that the 16-byte-per-lane
+            # gather (and its hub-row pass) can take; zero columns change no result
+            pad = width - x.size(1)
+            x = default_cache().padded(x, width)
+            w_l, w_r = F.pad(w_l, (0, pad)), F.pad(w_r, (0, pad))
+        return SAGELayerFunction.apply(x, w_l, self.lin_l.bias, w_r, graph, epilogue, p, seed,
+                                       keep_mask, force_generic)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         graph = default_cache().get(edge_index, x.size(0))

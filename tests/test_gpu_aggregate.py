@@ -26,7 +26,7 @@ def test_kat1_exact():
     assert torch.equal(agg.cpu(), torch.tensor(k["agg"]))
 
 
-@pytest.mark.parametrize("f", [7, 64, 128, 256, 32, 16, 1, 5, 100, 300])
+@pytest.mark.parametrize("f", [7, 8, 4, 64, 128, 256, 32, 16, 1, 5, 100, 300])
 def test_forward_matches_oracle(f):
     from graphsage_amd.graph import build_csr
     from graphsage_amd.ops import aggregate_mean
@@ -57,7 +57,7 @@ def test_backward_matches_autograd_of_oracle(f):
     assert_close(got2.cpu(), x.grad + base)
 
 
-@pytest.mark.parametrize("f", [64, 7, 256])
+@pytest.mark.parametrize("f", [64, 7, 8, 256])
 def test_hub_rows_and_isolated_rows(f):
     from graphsage_amd import _lib
     from graphsage_amd.graph import build_csr
