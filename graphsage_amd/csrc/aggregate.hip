@@ -95,18 +95,33 @@ seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
                  const float *__restrict__ row_scale, const float *__restrict__ ew,
                  const float *__restrict__ x, const float *add_to, int64_t N, int64_t F,
                  float *out, int long_t) {
+  constexpr int G = 64 / LPR;
   const int lane = gs_lane();
   const int slot = lane / LPR, sub = lane % LPR;
   const int64_t wave0 = (int64_t)blockIdx.x * (AGG_BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (AGG_BLOCK / 64);
-  for (int64_t row = wave0; row < N; row += nwaves) {
-    int p0 = rowptr[row], p1 = rowptr[row + 1];
-    if (long_t > 0 && p1 - p0 > long_t) continue;  // hub pass owns this row
-    float4 acc = gather_range<LPR, WEIGHTED>(col, x, ew, F, p0, p1);
-    acc = group_reduce<LPR>(acc);
-    if (slot == 0) {
+  // a wave takes G consecutive rows per iteration and stores them with ONE full-wave
+  // 1-KiB store (lane group g keeps row g's sum)
+  for (int64_t rg = wave0 * G; rg < N; rg += nwaves * G) {
+    float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool mine = false;
+#pragma unroll 1
+    for (int i = 0; i < G; ++i) {
+      int64_t row = rg + i;
+      if (row >= N) break;
+      int p0 = rowptr[row], p1 = rowptr[row + 1];
+      if (long_t > 0 && p1 - p0 > long_t) continue;  // hub pass owns this row
+      float4 acc = gather_range<LPR, WEIGHTED>(col, x, ew, F, p0, p1);
+      acc = group_reduce<LPR>(acc);
+      if (slot == i) {
+        keep = acc;
+        mine = true;
+      }
+    }
+    if (mine) {
+      int64_t row = rg + slot;
       float s = row_scale ? row_scale[row] : 1.f;
-      float4 o = make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s);
+      float4 o = make_float4(keep.x * s, keep.y * s, keep.z * s, keep.w * s);
       int64_t off = row * F + sub * 4;
       if (add_to) {
         float4 a = *(const float4 *)(add_to + off);

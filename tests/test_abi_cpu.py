@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library loads, exports every symbol include/gsage.h declares, and the
+host-only entry points behave; the product path refuses CPU tensors (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "gsage.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsage_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from graphsage_amd import _lib
+    names = _declared()
+    assert len(names) >= 13
+    lib = ctypes.CDLL(_lib.lib_path())
+    for n in names:
+        assert hasattr(lib, n), f"libgsage.so does not export {n}"
+    assert sorted(_lib.SIGNATURES) == names        # python binding covers the header 1:1
+
+
+def test_host_only_entry_points():
+    from graphsage_amd import _lib
+    lib = _lib.load()
+    assert lib.gsage_version() == 100
+    assert lib.gsage_error_string(0) == b"ok"
+    assert b"workspace" in lib.gsage_error_string(-3)
+    assert lib.gsage_long_row_threshold() > 64
+    assert lib.gsage_csr_workspace_bytes(0, 0) > 0
+    small, big = lib.gsage_csr_workspace_bytes(1000, 100), lib.gsage_csr_workspace_bytes(10**6, 10**5)
+    assert big > small >= 6 * 4 * 1000
+    assert lib.gsage_project_workspace_bytes(64, 64) >= 2 * 64 * 64 * 4
+    assert lib.gsage_project_bwd_workspace_bytes(10**6, 64, 64) > lib.gsage_project_workspace_bytes(64, 64)
+    assert lib.gsage_skipgram_workspace_bytes(1024) > 0
+    assert lib.gsage_csr_workspace_bytes(-1, 5) == 0
+
+
+def test_argument_validation_without_gpu():
+    """Entry points check their arguments before touching the device."""
+    from graphsage_amd import _lib
+    lib = _lib.load()
+    assert lib.gsage_segment_gather(None, None, None, None, None, None, 10, 64, None, None, None, None) == -1
+    assert lib.gsage_csr_build(None, 5, 5, None, None, None, None, None, None, None, 0, None, None, None, 0, None) == -1
+    assert lib.gsage_project_fwd(None, None, None, None, None, 4, 7, 64, 0, None, 0, 0.0, None, None, None, 0, None) == -1
+    assert lib.gsage_skipgram_fwd(None, 4, 64, None, None, None, 8, 5, 5.0, 8.0, 40.0, None, None, None, 0, None) == -1
+    with pytest.raises(ValueError):
+        _lib.check(-1, "x")
+    with pytest.raises(RuntimeError):
+        _lib.check(-4, "x")
+
+
+def test_product_path_has_no_cpu_fallback():
+    from graphsage_amd import GraphSAGE, SkipGramLoss
+    m = GraphSAGE()
+    with pytest.raises(ValueError, match="GPU"):
+        m(torch.randn(10, 7), torch.randint(0, 10, (2, 30)))
+    with pytest.raises(ValueError, match="GPU|CPU"):
+        SkipGramLoss()(torch.randn(10, 64), torch.tensor([1]), torch.tensor([2]), torch.tensor([[3]]))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "graphsage_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read(), f

@@ -1,0 +1,126 @@
+"""CPU: host-side logic of the drop-in classes (no kernel launches)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sage_oracle as O
+
+
+def test_graphsage_contract_matches_reference_class():
+    """Constructor defaults, attributes and state_dict layout of src/model/graphsage.py:68-157."""
+    from graphsage_amd import GraphSAGE
+    m = GraphSAGE()
+    assert (m.in_channels, m.hidden_channels, m.out_channels, m.num_layers) == (7, 64, 64, 2)
+    assert m.dropout_rate == 0.3 and m.normalize_output is True and isinstance(m.dropout, torch.nn.Dropout)
+    assert m.count_parameters() == 9216 and m.get_embedding_dim() == 64
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {
+        "convs.0.lin_l.weight": (64, 7), "convs.0.lin_l.bias": (64,), "convs.0.lin_r.weight": (64, 7),
+        "convs.1.lin_l.weight": (64, 64), "convs.1.lin_l.bias": (64,), "convs.1.lin_r.weight": (64, 64)}
+    ref = O.OracleGraphSAGE()
+    m.load_state_dict(ref.state_dict(), strict=True)
+    ref.load_state_dict(m.state_dict(), strict=True)
+    assert len(GraphSAGE(num_layers=1).convs) == 1 and len(GraphSAGE(num_layers=4).convs) == 4
+    with pytest.raises(ValueError):
+        GraphSAGE(aggregator="max")
+    before = m.convs[0].lin_l.weight.clone()
+    m.reset_parameters()
+    assert not torch.equal(before, m.convs[0].lin_l.weight)
+
+
+def test_create_model_and_loss_factories():
+    from graphsage_amd import SkipGramLoss, create_loss, create_model
+    cfg = {"features": {"dimensions": 7}, "model": {"hidden_dim": 128, "output_dim": 32, "num_layers": 3,
+                                                    "dropout": 0.1, "normalize_output": False}}
+    m = create_model(cfg)
+    assert (m.hidden_channels, m.out_channels, m.num_layers, m.dropout_rate, m.normalize_output) == \
+        (128, 32, 3, 0.1, False)
+    assert isinstance(create_loss("skipgram", scale_factor=2.0), SkipGramLoss)
+    assert create_loss().scale_factor == 5.0
+    with pytest.raises(ValueError):
+        create_loss("margin")
+
+
+def test_vector_width_rule():
+    from graphsage_amd.graphsage import vector_width
+    assert [vector_width(f) for f in (7, 8, 3, 4, 64, 100, 128, 200, 256)] == [8, 8, 4, 4, 64, 128, 128, 256, 256]
+    assert vector_width(5) == 5 and vector_width(20) == 20 and vector_width(300) == 300   # pad too costly
+
+
+def test_shard_bounds_cover_everything_once():
+    from graphsage_amd import shard_bounds
+    for total in (0, 1, 7, 1024, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_flat_params_alias_module_parameters():
+    from graphsage_amd import FlatParams
+    torch.manual_seed(0)
+    m = O.OracleGraphSAGE()
+    want = [p.detach().clone() for p in m.parameters()]
+    fp = FlatParams(m)
+    assert fp.numel == 9216 and fp.buf.numel() == 9216 + 8
+    for p, w in zip(m.parameters(), want):
+        assert torch.equal(p.detach(), w)
+    x, ei = torch.randn(50, 7), torch.randint(0, 50, (2, 300))
+    m(x, ei).sum().backward()
+    m(x, ei).sum().backward()                      # accumulates in place into the flat buffer
+    off = 0
+    for p in m.parameters():
+        assert p.grad.data_ptr() == fp.flat_grad[off:].data_ptr()
+        off += p.numel()
+    assert fp.flat_grad.abs().sum() > 0
+    fp.flat.add_(1.0)                              # optimiser writes the flat tensor ...
+    for p, w in zip(m.parameters(), want):         # ... and the module sees it
+        assert torch.allclose(p.detach(), w + 1.0)
+    fp.zero_grad()
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in m.parameters())
+
+
+def test_dropout_hash_mirror_statistics():
+    from graphsage_amd.rng import dropout_keep_mask
+    m1 = dropout_keep_mask(123, 1000, 64, 0.3)
+    m2 = dropout_keep_mask(123, 1000, 64, 0.3)
+    m3 = dropout_keep_mask(124, 1000, 64, 0.3)
+    assert np.array_equal(m1, m2) and not np.array_equal(m1, m3)
+    assert abs(m1.mean() - 0.7) < 0.01
+    assert abs(m1.mean(axis=0) - 0.7).max() < 0.06 and abs(m1.mean(axis=1) - 0.7).max() < 0.25
+    assert dropout_keep_mask(5, 10, 10, 0.0).all()
+
+
+def test_synthetic_graph_matches_view_extractor_contract():
+    """Same layout as src/data/view_extractor.py:182-188 leaves: symmetric, unique, sorted."""
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    n = 20000
+    ei = powerlaw_graph(n, 20, seed=42)
+    assert ei.dtype == torch.int64 and ei.shape[0] == 2
+    key = ei[0] * n + ei[1]
+    assert bool((key[1:] > key[:-1]).all())
+    assert torch.equal(torch.sort(ei[1] * n + ei[0]).values, key)
+    assert bool((ei[0] != ei[1]).all())
+    deg = torch.bincount(ei[0], minlength=n)
+    assert 15 < deg.float().mean() < 21 and deg.max() > 20 * deg.float().median()   # heavy tail
+    assert torch.equal(ei, powerlaw_graph(n, 20, seed=42))
+    x = memory_features(n)
+    assert x.shape == (n, 7) and x[:, :4].min() >= 0 and x[:, :4].max() <= 1
+    assert set(x[:, 4:].unique().tolist()) <= {0.0, 1.0}
+    t, c, neg = cooccurrence_batch(ei, n, 4096, 5)
+    assert t.shape == (4096,) and c.shape == (4096,) and neg.shape == (4096, 5)
+    assert int(deg[t].min()) > 0 and 0 <= int(neg.min()) and int(neg.max()) < n
+    # degree bias of negatives (tests/test_walks.py:170-186 of the reference, same idea)
+    assert deg[neg.flatten()].float().mean() > 2 * deg.float().mean()
+
+
+def test_stats_to_details_keys_and_index_error():
+    from graphsage_amd.loss import DETAIL_KEYS, stats_to_details
+    d = stats_to_details(torch.tensor([3.0, 1.0, 2.0, 0.1, -0.1, 0.6, 0.4, 0.0]))
+    assert tuple(d) == DETAIL_KEYS == ("total_loss", "pos_loss", "neg_loss", "pos_score_mean",
+                                       "neg_score_mean", "pos_prob", "neg_prob")       # loss.py:185-193
+    assert d["total_loss"] == 3.0 and all(isinstance(v, float) for v in d.values())
+    with pytest.raises(IndexError):
+        stats_to_details(torch.tensor([0.0] * 7 + [1.0]))
