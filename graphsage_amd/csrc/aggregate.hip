@@ -9,14 +9,16 @@
 // are fetched 64 at a time with one coalesced load and handed to the lanes with
 // ds_bpermute (the LDS crossbar; no LDS memory is touched).  Sums are kept in
 // registers and combined across the G lane groups by xor-shuffles in a fixed order,
-// so results are bitwise reproducible.  Rows longer than the hub threshold are left
-// to a second launch that gives a whole 1024-thread workgroup to each of them.
+// so results are bitwise reproducible.  Rows longer than the hub threshold are taken by
+// the first HUB_BLOCKS workgroups of the same launch (dispatched first, so the long rows
+// overlap the rest of the grid): 4 waves share a hub row in interleaved 64-neighbour
+// chunks and combine through LDS in wave order.
 #include "gsage_common.h"
 
 namespace {
 
 constexpr int AGG_BLOCK = 256;         // 4 waves, one row per wave per iteration
-constexpr int HUB_BLOCK = 1024;        // 16 waves per hub row
+constexpr int HUB_BLOCKS = 256;        // leading workgroups that walk the hub-row list
 
 template <int LPR>
 __device__ __forceinline__ float4 group_reduce(float4 a) {
@@ -88,18 +90,70 @@ __device__ __forceinline__ float4 gather_range(const int *__restrict__ col,
   return acc;
 }
 
+// hub rows: one workgroup (4 waves) per row; waves take interleaved 64-neighbour chunks,
+// partial sums are combined through LDS in wave order (fixed => reproducible).
+template <int LPR, bool WEIGHTED>
+__device__ __forceinline__ void hub_rows(const int *__restrict__ rowptr, const int *__restrict__ col,
+                                         const float *__restrict__ row_scale,
+                                         const float *__restrict__ ew, const float *__restrict__ x,
+                                         const float *add_to, int64_t F, float *out,
+                                         const int *__restrict__ long_rows,
+                                         const int *__restrict__ n_long, int hub_blocks) {
+  constexpr int NW = AGG_BLOCK / 64;
+  __shared__ float4 part[NW][LPR];
+  const int lane = gs_lane(), wave = threadIdx.x >> 6;
+  const int slot = lane / LPR, sub = lane % LPR;
+  const int nl = *n_long;
+  for (int li = blockIdx.x; li < nl; li += hub_blocks) {
+    int64_t row = long_rows[li];
+    int p0 = rowptr[row], p1 = rowptr[row + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pc = p0 + wave * 64; pc < p1; pc += NW * 64) {
+      int pe = pc + 64 < p1 ? pc + 64 : p1;
+      float4 r = gather_range<LPR, WEIGHTED>(col, x, ew, F, pc, pe);
+      acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+    }
+    acc = group_reduce<LPR>(acc);
+    if (slot == 0) part[wave][sub] = acc;
+    __syncthreads();
+    if (wave == 0 && slot == 0) {
+      float4 t = part[0][sub];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        float4 q = part[w][sub];
+        t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+      }
+      float s = row_scale ? row_scale[row] : 1.f;
+      float4 o = make_float4(t.x * s, t.y * s, t.z * s, t.w * s);
+      int64_t off = row * F + sub * 4;
+      if (add_to) {
+        float4 a = *(const float4 *)(add_to + off);
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      }
+      *(float4 *)(out + off) = o;
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- vector path, F = 4*LPR
 template <int LPR, bool WEIGHTED>
 __global__ void __launch_bounds__(AGG_BLOCK)
 seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
                  const float *__restrict__ row_scale, const float *__restrict__ ew,
                  const float *__restrict__ x, const float *add_to, int64_t N, int64_t F,
-                 float *out, int long_t) {
+                 float *out, int long_t, const int *__restrict__ long_rows,
+                 const int *__restrict__ n_long, int hub_blocks) {
+  if ((int)blockIdx.x < hub_blocks) {
+    hub_rows<LPR, WEIGHTED>(rowptr, col, row_scale, ew, x, add_to, F, out, long_rows, n_long,
+                            hub_blocks);
+    return;
+  }
   constexpr int G = 64 / LPR;
   const int lane = gs_lane();
   const int slot = lane / LPR, sub = lane % LPR;
-  const int64_t wave0 = (int64_t)blockIdx.x * (AGG_BLOCK / 64) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (AGG_BLOCK / 64);
+  const int64_t wave0 = (int64_t)(blockIdx.x - hub_blocks) * (AGG_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)(gridDim.x - hub_blocks) * (AGG_BLOCK / 64);
   // a wave takes G consecutive rows per iteration and stores them with ONE full-wave
   // 1-KiB store (lane group g keeps row g's sum)
   for (int64_t rg = wave0 * G; rg < N; rg += nwaves * G) {
@@ -129,51 +183,6 @@ seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
       }
       *(float4 *)(out + off) = o;
     }
-  }
-}
-
-// hub rows: one 16-wave workgroup per row; waves take interleaved 64-neighbour chunks,
-// partial sums are combined through LDS in wave order (fixed => reproducible).
-template <int LPR, bool WEIGHTED>
-__global__ void __launch_bounds__(HUB_BLOCK)
-seg_gather_hub_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
-                     const float *__restrict__ row_scale, const float *__restrict__ ew,
-                     const float *__restrict__ x, const float *add_to, int64_t F, float *out,
-                     const int *__restrict__ long_rows, const int *__restrict__ n_long,
-                     int64_t long_cap) {
-  __shared__ float4 part[HUB_BLOCK / 64][LPR];
-  const int lane = gs_lane(), wave = threadIdx.x >> 6;
-  const int slot = lane / LPR, sub = lane % LPR;
-  int nl = *n_long;
-  if (nl > long_cap) nl = (int)long_cap;
-  for (int li = blockIdx.x; li < nl; li += gridDim.x) {
-    int64_t row = long_rows[li];
-    int p0 = rowptr[row], p1 = rowptr[row + 1];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int pc = p0 + wave * 64; pc < p1; pc += (HUB_BLOCK / 64) * 64) {
-      int pe = pc + 64 < p1 ? pc + 64 : p1;
-      float4 r = gather_range<LPR, WEIGHTED>(col, x, ew, F, pc, pe);
-      acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
-    }
-    acc = group_reduce<LPR>(acc);
-    if (slot == 0) part[wave][sub] = acc;
-    __syncthreads();
-    if (wave == 0 && slot == 0) {
-      float4 t = part[0][sub];
-      for (int w = 1; w < HUB_BLOCK / 64; ++w) {
-        float4 q = part[w][sub];
-        t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
-      }
-      float s = row_scale ? row_scale[row] : 1.f;
-      float4 o = make_float4(t.x * s, t.y * s, t.z * s, t.w * s);
-      int64_t off = row * F + sub * 4;
-      if (add_to) {
-        float4 a = *(const float4 *)(add_to + off);
-        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-      }
-      *(float4 *)(out + off) = o;
-    }
-    __syncthreads();
   }
 }
 
@@ -227,27 +236,20 @@ template <int LPR>
 int launch_vec(const int *rowptr, const int *col, const float *row_scale, const float *ew,
                const float *x, const float *add_to, int64_t N, int64_t F, float *out,
                const int *long_rows, const int *n_long, hipStream_t st) {
-  int grid = gs_grid(N, AGG_BLOCK / 64, 256 * 64);
-  int long_t = (long_rows && n_long) ? gsage_long_row_threshold() : 0;
-  int64_t long_cap = 0x7fffffff;
+  constexpr int G = 64 / LPR;
+  const bool hubs = long_rows && n_long;
+  const int long_t = hubs ? gsage_long_row_threshold() : 0;
+  const int hub_blocks = hubs ? HUB_BLOCKS : 0;
+  const int grid = gs_grid(N, (AGG_BLOCK / 64) * G, 256 * 64) + hub_blocks;
   if (ew)
     hipLaunchKernelGGL((seg_gather_vec_k<LPR, true>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
-                       col, row_scale, ew, x, add_to, N, F, out, long_t);
+                       col, row_scale, ew, x, add_to, N, F, out, long_t, long_rows, n_long,
+                       hub_blocks);
   else
     hipLaunchKernelGGL((seg_gather_vec_k<LPR, false>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
-                       col, row_scale, ew, x, add_to, N, F, out, long_t);
+                       col, row_scale, ew, x, add_to, N, F, out, long_t, long_rows, n_long,
+                       hub_blocks);
   GSAGE_CHECK_LAUNCH();
-  if (long_t > 0) {
-    if (ew)
-      hipLaunchKernelGGL((seg_gather_hub_vec_k<LPR, true>), dim3(256), dim3(HUB_BLOCK), 0, st,
-                         rowptr, col, row_scale, ew, x, add_to, F, out, long_rows, n_long,
-                         long_cap);
-    else
-      hipLaunchKernelGGL((seg_gather_hub_vec_k<LPR, false>), dim3(256), dim3(HUB_BLOCK), 0, st,
-                         rowptr, col, row_scale, ew, x, add_to, F, out, long_rows, n_long,
-                         long_cap);
-    GSAGE_CHECK_LAUNCH();
-  }
   return GSAGE_OK;
 }
 

@@ -22,12 +22,18 @@ constexpr float L2_EPS = 1e-12f;
 
 // ------------------------------------------------------------------ dropout hash RNG
 // keep(seed, idx) with idx = row*Fo + col; mirrored in graphsage_amd/rng.py for tests.
+// 32-bit arithmetic only (64-bit multiplies are emulated on the VALU): a bijective scramble
+// of the element index keyed by the seed, then murmur3's fmix32 avalanche.
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, float p) {
-  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  float u = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0,1)
+  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  uint32_t h = (uint32_t)seed ^ (lo * 0x9E3779B1u);
+  h ^= (uint32_t)(seed >> 32) + hi * 0x85EBCA77u;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  float u = (float)(h >> 8) * (1.0f / 16777216.0f);  // 24 random bits -> [0,1)
   return u >= p;
 }
 
@@ -348,6 +354,247 @@ dw_mfma_k(const float *__restrict__ dpre, const float *__restrict__ agg,
   if (nt == 0 && t < 64) slab[(int64_t)Fo * K2 + m0 + t] = bsum;
 }
 
+
+// ======================================================================= 64 -> 64 layer
+// The headline shape (hidden = out = 64).  Persistent workgroups walk 64-row tiles; the
+// packed weights live in REGISTERS in MFMA B-operand order for the whole launch (a wave's
+// 32 output columns x K), so per tile only the activations move: global -> LDS (whole K at
+// once, pitch 132 floats => conflict-free ds_read_b128) -> MFMA.  Several workgroups per CU
+// overlap one tile's loads with another's MFMAs.
+constexpr int S64_AP = 132;   // pitch of the [agg | x] tile (128 columns)
+constexpr int S64_DP = 68;    // pitch of a 64-column tile
+
+__device__ __forceinline__ float f4c(const float4 &v, int s) {
+  return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w;
+}
+
+// stage rows [row0, row0+64) of [a1 | a2] (64 columns each) into tile[64][S64_AP]
+__device__ __forceinline__ void s64_stage_cat(const float *__restrict__ a1,
+                                              const float *__restrict__ a2, int64_t row0,
+                                              int64_t M, float *tile) {
+  const int t = threadIdx.x;
+  float4 r1[4], r2[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    int64_t row = row0 + p * 16 + (t >> 4);
+    int c = (t & 15) * 4;
+    if (row < M) {
+      r1[p] = *(const float4 *)(a1 + row * 64 + c);
+      r2[p] = *(const float4 *)(a2 + row * 64 + c);
+    } else {
+      r1[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      r2[p] = r1[p];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    int r = p * 16 + (t >> 4), c = (t & 15) * 4;
+    *(float4 *)(tile + r * S64_AP + c) = r1[p];
+    *(float4 *)(tile + r * S64_AP + 64 + c) = r2[p];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
+             const float *__restrict__ bp /* [64][128] */, int64_t M, EpiArgs e,
+             float *__restrict__ out) {
+  __shared__ __align__(16) float As[64 * S64_AP];
+  __shared__ __align__(16) float Cs[64 * S64_DP];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  float4 breg[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+    breg[g] = *(const float4 *)(bp + (wn * 32 + (lane & 31)) * 128 + g * 8 + (lane >> 5) * 4);
+  const int rsub = t >> 4, c4 = (t & 15) * 4;
+  const float4 bias = *(const float4 *)(e.bias + c4);
+  const int64_t ntiles = (M + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * 64;
+    s64_stage_cat(agg, x, row0, M, As);
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float *arow = As + (wm * 32 + (lane & 31)) * S64_AP + (lane >> 5) * 4;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float4 af = *(const float4 *)(arow + g * 8);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af, s2), f4c(breg[g], s2), acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      Cs[row * S64_DP + wn * 32 + (lane & 31)] = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      int r = pass * 16 + rsub;
+      int64_t grow = row0 + r;
+      bool live = grow < M;
+      float4 v = *(const float4 *)(Cs + r * S64_DP + c4);
+      v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+      if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (e.mode == GSAGE_EPI_RELU_DROPOUT && live) {
+        uint64_t idx = (uint64_t)grow * 64u + (uint64_t)c4;
+        bool k0, k1, k2, k3;
+        if (e.keep_mask) {
+          uchar4 m = *(const uchar4 *)(e.keep_mask + idx);
+          k0 = m.x; k1 = m.y; k2 = m.z; k3 = m.w;
+        } else {
+          k0 = dropout_keep(e.seed, idx + 0, e.p); k1 = dropout_keep(e.seed, idx + 1, e.p);
+          k2 = dropout_keep(e.seed, idx + 2, e.p); k3 = dropout_keep(e.seed, idx + 3, e.p);
+        }
+        v.x = k0 ? v.x * e.inv_keep : 0.f; v.y = k1 ? v.y * e.inv_keep : 0.f;
+        v.z = k2 ? v.z * e.inv_keep : 0.f; v.w = k3 ? v.w * e.inv_keep : 0.f;
+      }
+      if (e.mode == GSAGE_EPI_L2NORM) {
+        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 4, 64);
+        ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 1, 64);
+        float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
+        v.x *= rn; v.y *= rn; v.z *= rn; v.w *= rn;
+        if (live && (t & 15) == 0 && e.rnorm) e.rnorm[grow] = rn;
+      }
+      if (live) *(float4 *)(out + grow * 64 + c4) = v;
+    }
+    // the next tile's staging overwrites As only: every wave has passed the barrier above,
+    // i.e. finished its MFMA reads of As; Cs is rewritten only after the next barrier
+  }
+}
+
+// Fused backward of a 64 -> 64 layer: per 64-row tile
+//   dpre = epi'(grad_out)                      (registers -> LDS, never written to HBM)
+//   [grad_agg | grad_x] = dpre . [W_l | W_r]   (MFMA, weights in registers; grad_agg * scale)
+//   dW += dpre^T . [agg | x], db += colsum     (MFMA over the row index, kept in registers
+//                                               across the workgroup's tiles -> one slab)
+__global__ void __launch_bounds__(256)
+bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
+              const float *__restrict__ rnorm, const float *__restrict__ agg,
+              const float *__restrict__ x, const float *__restrict__ bp /* [128][64] */,
+              const float *__restrict__ agg_scale, int64_t M, int mode, float inv_keep,
+              float *__restrict__ grad_agg, float *__restrict__ grad_x,
+              float *__restrict__ slabs) {
+  __shared__ __align__(16) float Ac[64 * S64_AP];
+  __shared__ __align__(16) float Dp[64 * S64_DP];
+  __shared__ float sc[64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int rt = w & 1, cp = w >> 1;   // dX: row tile rt, column tiles 2cp, 2cp+1
+  float4 breg[2][8];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int gi = 0; gi < 8; ++gi)
+      breg[j][gi] = *(const float4 *)(bp + ((2 * cp + j) * 32 + (lane & 31)) * 64 + gi * 8 +
+                                      (lane >> 5) * 4);
+  f32x16 dw0, dw1;   // dW tiles: rows m = 0..31 / 32..63, columns 32w .. 32w+31 of [agg | x]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; }
+  float bsum = 0.f;
+  const int rsub = t >> 4, c4 = (t & 15) * 4;
+  const int64_t ntiles = (M + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * 64;
+    // ---- dpre tile
+    {
+      float4 gv[4], yv[4];
+      float rn[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        int64_t row = row0 + p * 16 + rsub;
+        if (row < M) {
+          gv[p] = *(const float4 *)(g + row * 64 + c4);
+          yv[p] = mode != GSAGE_EPI_NONE ? *(const float4 *)(y + row * 64 + c4) : gv[p];
+          rn[p] = mode == GSAGE_EPI_L2NORM ? rnorm[row] : 1.f;
+        } else {
+          gv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+          yv[p] = gv[p];
+          rn[p] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float4 d = gv[p];
+        if (mode == GSAGE_EPI_L2NORM) {
+          float dot = gv[p].x * yv[p].x + gv[p].y * yv[p].y + gv[p].z * yv[p].z + gv[p].w * yv[p].w;
+          dot += __shfl_xor(dot, 8, 64); dot += __shfl_xor(dot, 4, 64);
+          dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 1, 64);
+          if (rn[p] >= 0.5f / L2_EPS) dot = 0.f;   // clamped norm: dy/dx = I / eps
+          d.x = (gv[p].x - yv[p].x * dot) * rn[p]; d.y = (gv[p].y - yv[p].y * dot) * rn[p];
+          d.z = (gv[p].z - yv[p].z * dot) * rn[p]; d.w = (gv[p].w - yv[p].w * dot) * rn[p];
+        } else if (mode != GSAGE_EPI_NONE) {
+          d.x = yv[p].x > 0.f ? d.x * inv_keep : 0.f; d.y = yv[p].y > 0.f ? d.y * inv_keep : 0.f;
+          d.z = yv[p].z > 0.f ? d.z * inv_keep : 0.f; d.w = yv[p].w > 0.f ? d.w * inv_keep : 0.f;
+        }
+        *(float4 *)(Dp + (p * 16 + rsub) * S64_DP + c4) = d;
+      }
+    }
+    s64_stage_cat(agg, x, row0, M, Ac);
+    if (t < 64) sc[t] = (agg_scale && row0 + t < M) ? agg_scale[row0 + t] : 1.f;
+    __syncthreads();
+    // ---- dX
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    const float *drow = Dp + (rt * 32 + (lane & 31)) * S64_DP + (lane >> 5) * 4;
+#pragma unroll
+    for (int gi = 0; gi < 8; ++gi) {
+      float4 af = *(const float4 *)(drow + gi * 8);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af, s2), f4c(breg[0][gi], s2), a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af, s2), f4c(breg[1][gi], s2), a1, 0, 0, 0);
+      }
+    }
+    // ---- dW (row index = MFMA K)
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      int kr = 2 * kk + (lane >> 5);
+      float d0 = Dp[kr * S64_DP + (lane & 31)];
+      float d1 = Dp[kr * S64_DP + 32 + (lane & 31)];
+      float b = Ac[kr * S64_AP + w * 32 + (lane & 31)];
+      dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, b, dw0, 0, 0, 0);
+      dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, b, dw1, 0, 0, 0);
+    }
+    if (t < 64) {
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) bsum += Dp[k * S64_DP + t];
+    }
+    // ---- dX stores straight from the accumulators (128-byte row segments)
+    {
+      float *dst = cp == 0 ? grad_agg : grad_x;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int64_t grow = row0 + lr;
+        float s = cp == 0 ? sc[lr] : 1.f;
+        if (grow < M) {
+          dst[grow * 64 + (lane & 31)] = a0[r] * s;
+          dst[grow * 64 + 32 + (lane & 31)] = a1[r] * s;
+        }
+      }
+    }
+    __syncthreads();   // all reads of Dp / Ac / sc done before the next tile restages them
+  }
+  float *slab = slabs + (int64_t)blockIdx.x * (64 * 128 + 64);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int mrow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    int ncol = w * 32 + (lane & 31);
+    slab[mrow * 128 + ncol] = dw0[r];
+    slab[(32 + mrow) * 128 + ncol] = dw1[r];
+  }
+  if (t < 64) slab[64 * 128 + t] = bsum;
+}
+
+constexpr int S64_GRID = 256 * 3;   // persistent workgroups (3 per CU fit LDS)
+constexpr int S64_BWD_GRID = 256 * 2;
+
 // =============================================================================== VALU
 // small-K forward (2*Fi <= 16, Fo <= 64): wave per row, lane = output column, weights in
 // registers, the row's 2*Fi inputs fetched by one load and broadcast with v_readlane.
@@ -478,9 +725,11 @@ dx_generic_k(const float *__restrict__ dpre, const float *__restrict__ wl,
 // small-K dW (2*Fi <= 16, Fo <= 64): lane = output row m of dW, K2MAX accumulators.
 template <int K2MAX>
 __global__ void __launch_bounds__(256)
-dw_smallk_k(const float *__restrict__ dpre, const float *__restrict__ agg,
-            const float *__restrict__ x, int64_t M, int Fi, int Fo, int64_t rows_per_block,
-            float *__restrict__ slabs) {
+dw_smallk_k(const float *__restrict__ dpre, const float *__restrict__ out_saved, int relu_mode,
+            float inv_keep, const float *__restrict__ agg, const float *__restrict__ x, int64_t M,
+            int Fi, int Fo, int64_t rows_per_block, float *__restrict__ slabs) {
+  // relu_mode != 0: `dpre` holds grad_out and the ReLU(+dropout) derivative is applied here
+  // from the saved output (out > 0 <=> pre > 0 and kept), saving the dpre round trip
   __shared__ float red[4][K2MAX + 1][64];
   const int lane = gs_lane(), w = threadIdx.x >> 6;
   const int K2 = 2 * Fi;
@@ -492,6 +741,7 @@ dw_smallk_k(const float *__restrict__ dpre, const float *__restrict__ agg,
   for (int k = 0; k <= K2MAX; ++k) acc[k] = 0.f;
   for (int64_t row = r_begin + w; row < r_end; row += 4) {
     float d = lane < Fo ? dpre[row * Fo + lane] : 0.f;
+    if (relu_mode && lane < Fo) d = out_saved[row * Fo + lane] > 0.f ? d * inv_keep : 0.f;
     float in = 0.f;
     if (lane < Fi) in = agg[row * Fi + lane];
     else if (lane < K2) in = x[row * Fi + lane - Fi];
@@ -602,7 +852,15 @@ extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *
   const int pack_grid = gs_grid(2 * Fi * Fo, 256, 64);
   const bool aligned = (((uintptr_t)agg | (uintptr_t)x | (uintptr_t)out | (uintptr_t)b_l |
                          (uintptr_t)keep_mask) & 15) == 0;
-  if (!force_generic && aligned && mfma_dim(Fi) && mfma_dim(Fo)) {
+  if (force_generic == 0 && aligned && Fi == 64 && Fo == 64) {
+    hipLaunchKernelGGL(pack_fwd_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
+    int64_t ntiles = (N + 63) / 64;
+    int grid = (int)(ntiles < S64_GRID ? ntiles : S64_GRID);
+    hipLaunchKernelGGL(proj64_fwd_k, dim3(grid), dim3(256), 0, st, agg, x, wp, N, e, out);
+    GSAGE_CHECK_LAUNCH();
+    return GSAGE_OK;
+  }
+  if (force_generic != 1 && aligned && mfma_dim(Fi) && mfma_dim(Fo)) {
     hipLaunchKernelGGL(pack_fwd_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
     GemmArgs a{};
     a.A1 = agg; a.A2 = x; a.Bp = wp; a.C1 = out; a.C2 = nullptr;
@@ -657,10 +915,34 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
     return GSAGE_OK;
   }
 
+  // 0. the 64 -> 64 layer: one fused pass (dpre never leaves the chip)
+  {
+    const bool al = (((uintptr_t)grad_out | (uintptr_t)out | (uintptr_t)agg | (uintptr_t)x |
+                      (uintptr_t)grad_agg | (uintptr_t)grad_x) & 15) == 0;
+    if (force_generic == 0 && al && Fi == 64 && Fo == 64 && grad_agg && grad_x) {
+      hipLaunchKernelGGL(pack_dx_k, dim3(gs_grid(2 * Fi * Fo, 256, 64)), dim3(256), 0, st, w_l, w_r,
+                         fi, fo, wp);
+      int grid = nslab < S64_BWD_GRID ? nslab : S64_BWD_GRID;
+      const float ik = epilogue == GSAGE_EPI_RELU_DROPOUT ? 1.0f / (1.0f - p) : 1.0f;
+      hipLaunchKernelGGL(bwd64_fused_k, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x,
+                         wp, agg_scale, N, epilogue, ik, grad_agg, grad_x, slabs);
+      GSAGE_CHECK_LAUNCH();
+      hipLaunchKernelGGL(reduce_slabs_k, dim3(gs_grid(2 * Fi * Fo + Fo, 256, 256)), dim3(256), 0,
+                         st, slabs, grid, fi, fo, grad_w_l, grad_w_r, grad_b);
+      GSAGE_CHECK_LAUNCH();
+      return GSAGE_OK;
+    }
+  }
+
   // 1. dpre
   const float *dp = grad_out;
-  if (epilogue != GSAGE_EPI_NONE) {
-    float inv_keep = epilogue == GSAGE_EPI_RELU_DROPOUT ? 1.0f / (1.0f - p) : 1.0f;
+  const float inv_keep = epilogue == GSAGE_EPI_RELU_DROPOUT ? 1.0f / (1.0f - p) : 1.0f;
+  const bool smallk = 2 * Fi <= 16 && Fo <= 64;
+  const bool relu_epi = epilogue == GSAGE_EPI_RELU || epilogue == GSAGE_EPI_RELU_DROPOUT;
+  // first layer in training: no input gradient wanted -> the ReLU derivative is applied
+  // inside the dW kernel and dpre is never materialised
+  const bool fuse_relu = smallk && relu_epi && !grad_agg && !grad_x;
+  if (epilogue != GSAGE_EPI_NONE && !fuse_relu) {
     hipLaunchKernelGGL(epilogue_bwd_k, dim3(gs_grid(N, 4, 256 * 16)), dim3(256), 0, st, grad_out,
                        out, rnorm, N, fo, epilogue, inv_keep, dpre);
     GSAGE_CHECK_LAUNCH();
@@ -668,7 +950,7 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
   }
   const bool aligned = (((uintptr_t)dp | (uintptr_t)agg | (uintptr_t)x | (uintptr_t)grad_agg |
                          (uintptr_t)grad_x) & 15) == 0;
-  const bool mfma = !force_generic && aligned && mfma_dim(Fi) && mfma_dim(Fo);
+  const bool mfma = force_generic != 1 && aligned && mfma_dim(Fi) && mfma_dim(Fo);
 
   // 2. input gradients
   if (grad_agg || grad_x) {
@@ -695,9 +977,9 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
   if (mfma) {
     dim3 grid((unsigned)nslab, (unsigned)((fo / 64) * (2 * fi / 128)));
     hipLaunchKernelGGL(dw_mfma_k, grid, dim3(256), 0, st, dp, agg, x, N, fi, fo, rpb, slabs);
-  } else if (2 * Fi <= 16 && Fo <= 64) {
-    hipLaunchKernelGGL((dw_smallk_k<16>), dim3(nslab), dim3(256), 0, st, dp, agg, x, N, fi, fo, rpb,
-                       slabs);
+  } else if (smallk) {
+    hipLaunchKernelGGL((dw_smallk_k<16>), dim3(nslab), dim3(256), 0, st, dp, out, fuse_relu ? 1 : 0,
+                       inv_keep, agg, x, N, fi, fo, rpb, slabs);
   } else {
     hipLaunchKernelGGL(dw_generic_k, dim3(nslab), dim3(256), 0, st, dp, agg, x, N, fi, fo, rpb,
                        slabs);

@@ -105,9 +105,10 @@ int gsage_segment_gather(const int32_t *rowptr, const int32_t *col,
  *               the kernel from (seed, element index); kept values are scaled 1/(1-p).
  *   rnorm     : fp32 [N], written for L2NORM: 1 / max(||row||, 1e-12) (saved for bwd).
  *   wpack     : fp32 workspace, gsage_project_workspace_bytes(Fi,Fo) bytes.
- *   fp32-input MFMA (v_mfma_f32_32x32x2_f32) when Fi % 16 == 0 and Fo in {64,128,256};
- *   a VALU kernel otherwise (e.g. the 7-wide first layer).  `force_generic` != 0
- *   selects the VALU kernel regardless (tests).
+ *   fp32-input MFMA (v_mfma_f32_32x32x2_f32) when Fi and Fo are in {64,128,256} (64 -> 64
+ *   has a specialised persistent kernel with the weights in registers); a VALU kernel
+ *   otherwise (e.g. the 8-wide first layer).  `force_generic`: 0 = choose by shape,
+ *   1 = VALU kernel regardless, 2 = generic MFMA tiles even for 64 -> 64 (tests).
  */
 size_t gsage_project_workspace_bytes(int64_t Fi, int64_t Fo);
 int gsage_project_fwd(const float *agg, const float *x, const float *w_l,

@@ -43,11 +43,13 @@ SHAPES = [(7, 64), (64, 64), (64, 128), (128, 128), (128, 64), (256, 256), (7, 3
 
 @pytest.mark.parametrize("epi", EPIS)
 @pytest.mark.parametrize("fi,fo", SHAPES)
-@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("force_generic", [0, 1, 2])
 def test_forward_backward(fi, fo, epi, force_generic):
     from graphsage_amd.ops import project_bwd, project_fwd
-    if force_generic and (fi, fo) not in [(64, 64), (128, 64), (7, 64)]:
-        pytest.skip("generic path already selected by shape")
+    if force_generic == 1 and (fi, fo) not in [(64, 64), (128, 64), (7, 64)]:
+        pytest.skip("VALU path already selected by shape")
+    if force_generic == 2 and (fi, fo) != (64, 64):
+        pytest.skip("only 64 -> 64 has a specialised kernel to bypass")
     n, p = 333, 0.3          # not a multiple of the 64-row tile
     agg, x, wl, bl, wr, keep, gout = _case(n, fi, fo, fi * 1000 + fo)
     leaves = [t.clone().requires_grad_() for t in (agg, x, wl, bl, wr)]
