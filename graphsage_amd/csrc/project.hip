@@ -766,6 +766,111 @@ dw_smallk_k(const float *__restrict__ dpre, const float *__restrict__ out_saved,
   }
 }
 
+
+// first-layer dW on the matrix cores (2*Fi <= 16 columns of [agg | x], Fo = 64):
+//   dW[m][k'] += dpre[row][m] * [agg | x][row][k'],  db[m] += dpre[row][m]
+// 16 lanes x 16 B cover one 64-float dpre row, so a wave holds 4 rows; those 4 rows are the K
+// dimension of v_mfma_f32_16x16x4_f32, float4 component c of a lane is tile c of dpre^T
+// (m = 4*sub + c) and the lane's single [agg | x] value is the B operand: 4 MFMAs per 4 rows,
+// no cross-lane traffic.  ReLU'(+dropout') is applied on the fly from the saved output.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int DW16_SLAB = 64 * 16 + 64;   // [m][k'] then bias[m]; k' < 8: agg col, else x col
+constexpr int DW16_BLOCKS = 256 * 4;
+
+__global__ void __launch_bounds__(256)
+dw16_mfma_k(const float *__restrict__ g, const float *__restrict__ y, int relu_mode,
+            float inv_keep, const float *__restrict__ agg, const float *__restrict__ x, int64_t M,
+            int Fi, float *__restrict__ slabs) {
+  __shared__ float red[4][17][64];
+  const int lane = gs_lane(), wave = threadIdx.x >> 6;
+  const int slot = lane >> 4, sub = lane & 15;
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  constexpr int U = 4;   // 4 row groups (16 rows) in flight per wave
+  for (int64_t r0 = wave0 * (4 * U); r0 < M; r0 += nwaves * (4 * U)) {
+    float4 d[U], yv[U];
+    float a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t row = r0 + u * 4 + slot;
+      bool live = row < M;
+      d[u] = live ? *(const float4 *)(g + row * 64 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      yv[u] = (live && relu_mode) ? *(const float4 *)(y + row * 64 + sub * 4)
+                                  : make_float4(1.f, 1.f, 1.f, 1.f);
+      float av = 0.f;
+      if (live) {
+        if (sub < 8) { if (sub < Fi) av = agg[row * Fi + sub]; }
+        else if (sub - 8 < Fi) av = x[row * Fi + sub - 8];
+      }
+      a[u] = av;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float4 v = d[u];
+      if (relu_mode) {
+        v.x = yv[u].x > 0.f ? v.x * inv_keep : 0.f; v.y = yv[u].y > 0.f ? v.y * inv_keep : 0.f;
+        v.z = yv[u].z > 0.f ? v.z * inv_keep : 0.f; v.w = yv[u].w > 0.f ? v.w * inv_keep : 0.f;
+      }
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, a[u], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, a[u], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, a[u], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, a[u], acc[3], 0, 0, 0);
+      bacc.x += v.x; bacc.y += v.y; bacc.z += v.z; bacc.w += v.w;
+    }
+  }
+  bacc.x += __shfl_xor(bacc.x, 16, 64); bacc.y += __shfl_xor(bacc.y, 16, 64);
+  bacc.z += __shfl_xor(bacc.z, 16, 64); bacc.w += __shfl_xor(bacc.w, 16, 64);
+  bacc.x += __shfl_xor(bacc.x, 32, 64); bacc.y += __shfl_xor(bacc.y, 32, 64);
+  bacc.z += __shfl_xor(bacc.z, 32, 64); bacc.w += __shfl_xor(bacc.w, 32, 64);
+  // acc[c][reg] of lane l = dW[m = 4*(4*(l>>4)+reg) + c][k' = l & 15]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][c * 4 + r][lane] = acc[c][r];
+  red[wave][16][lane] = slot == 0 ? bacc.x : slot == 1 ? bacc.y : slot == 2 ? bacc.z : bacc.w;
+  __syncthreads();
+  float *slab = slabs + (int64_t)blockIdx.x * DW16_SLAB;
+  for (int e = threadIdx.x; e < 17 * 64; e += 256) {
+    int q = e >> 6, l = e & 63;
+    float v = red[0][q][l] + red[1][q][l] + red[2][q][l] + red[3][q][l];
+    if (q < 16) {
+      int c = q >> 2, r = q & 3;
+      slab[(4 * (4 * (l >> 4) + r) + c) * 16 + (l & 15)] = v;
+    } else {
+      slab[64 * 16 + 4 * (l & 15) + (l >> 4)] = v;   // lane (slot, sub) holds m = 4*sub + slot
+    }
+  }
+}
+
+// lane = output element (coalesced over a slab's inner index); the 4 waves split the slabs
+// and combine through LDS in wave order.
+__global__ void __launch_bounds__(256)
+reduce_dw16_k(const float *__restrict__ slabs, int nslab, int Fi, float *__restrict__ gwl,
+              float *__restrict__ gwr, float *__restrict__ gb) {
+  __shared__ float red[4][64];
+  const int lane = gs_lane(), wave = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (e < DW16_SLAB)
+    for (int b = wave; b < nslab; b += 4) s += slabs[(int64_t)b * DW16_SLAB + e];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && e < DW16_SLAB) {
+    float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (e < 64 * 16) {
+      int m = e >> 4, k = e & 15;
+      if (k < 8) { if (k < Fi) gwl[m * Fi + k] = v; }
+      else if (k - 8 < Fi) gwr[m * Fi + k - 8] = v;
+    } else {
+      gb[e - 64 * 16] = v;
+    }
+  }
+}
+
 // generic dW: thread per output element, rows of the block's chunk in order.
 __global__ void __launch_bounds__(256)
 dw_generic_k(const float *__restrict__ dpre, const float *__restrict__ agg,
@@ -883,7 +988,8 @@ extern "C" size_t gsage_project_bwd_workspace_bytes(int64_t N, int64_t Fi, int64
   if (N < 0 || Fi <= 0 || Fo <= 0) return 0;
   size_t pack = gs_align_up((size_t)(2 * Fi * Fo) * sizeof(float), 256);
   size_t slabs = gs_align_up((size_t)num_slabs(N) * (size_t)(2 * Fi * Fo + Fo) * sizeof(float), 256);
-  return pack + slabs;
+  size_t slabs16 = (Fo == 64 && Fi <= 8) ? (size_t)DW16_BLOCKS * DW16_SLAB * sizeof(float) : 0;
+  return pack + (slabs > slabs16 ? slabs : slabs16);
 }
 
 extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const float *rnorm,
@@ -972,6 +1078,16 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
   }
 
   // 3. weight gradients: partial slabs, then an ordered sum
+  if (force_generic == 0 && Fo == 64 && Fi <= 8 && ((((uintptr_t)dp | (uintptr_t)out) & 15) == 0)) {
+    int grid = gs_grid(N, 64, DW16_BLOCKS);
+    hipLaunchKernelGGL(dw16_mfma_k, dim3(grid), dim3(256), 0, st, dp, out, fuse_relu ? 1 : 0,
+                       inv_keep, agg, x, N, fi, slabs);
+    GSAGE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_dw16_k, dim3((DW16_SLAB + 63) / 64), dim3(256), 0, st, slabs, grid, fi,
+                       grad_w_l, grad_w_r, grad_b);
+    GSAGE_CHECK_LAUNCH();
+    return GSAGE_OK;
+  }
   int64_t rpb = (N + nslab - 1) / nslab;
   rpb = (rpb + DW_RK - 1) / DW_RK * DW_RK;
   if (mfma) {

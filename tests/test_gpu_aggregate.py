@@ -98,3 +98,4 @@ def test_bitwise_reproducible_and_linear_at_c2_size():
     assert_close(ones, has_in)   # mean of ones is 1 (0 if isolated)
     ref = O.mean_aggregate(x.cpu(), ei.cpu())
     assert_close(a1.cpu(), ref)
+
