@@ -605,10 +605,11 @@ project_fwd_smallk_k(const float *__restrict__ agg, const float *__restrict__ x,
                      float *__restrict__ out) {
   const int lane = gs_lane();
   const int K2 = 2 * Fi;
+  const int col = blockIdx.y * 64 + lane;   // blockIdx.y: block of 64 output columns
   float wreg[K2MAX];
 #pragma unroll
-  for (int k = 0; k < K2MAX; ++k) wreg[k] = (k < K2 && lane < Fo) ? wt[k * Fo + lane] : 0.f;
-  const float bias = lane < Fo ? e.bias[lane] : 0.f;
+  for (int k = 0; k < K2MAX; ++k) wreg[k] = (k < K2 && col < Fo) ? wt[k * Fo + col] : 0.f;
+  const float bias = col < Fo ? e.bias[col] : 0.f;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   for (int64_t row = wave0; row < N; row += nwaves) {
@@ -622,18 +623,18 @@ project_fwd_smallk_k(const float *__restrict__ agg, const float *__restrict__ x,
       v = fmaf(ak, wreg[k], v);
     }
     if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) v = fmaxf(v, 0.f);
-    if (e.mode == GSAGE_EPI_RELU_DROPOUT && lane < Fo) {
-      uint64_t idx = (uint64_t)row * (uint64_t)Fo + (uint64_t)lane;
+    if (e.mode == GSAGE_EPI_RELU_DROPOUT && col < Fo) {
+      uint64_t idx = (uint64_t)row * (uint64_t)Fo + (uint64_t)col;
       bool keep = e.keep_mask ? (e.keep_mask[idx] != 0) : dropout_keep(e.seed, idx, e.p);
       v = keep ? v * e.inv_keep : 0.f;
     }
-    if (e.mode == GSAGE_EPI_L2NORM) {
-      float ss = gs_wave_sum(lane < Fo ? v * v : 0.f);
+    if (e.mode == GSAGE_EPI_L2NORM) {   // only launched with one column block (Fo <= 64)
+      float ss = gs_wave_sum(col < Fo ? v * v : 0.f);
       float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
       v *= rn;
       if (lane == 0 && e.rnorm) e.rnorm[row] = rn;
     }
-    if (lane < Fo) out[row * Fo + lane] = v;
+    if (col < Fo) out[row * Fo + col] = v;
   }
 }
 
@@ -780,7 +781,10 @@ constexpr int DW16_BLOCKS = 256 * 4;
 __global__ void __launch_bounds__(256)
 dw16_mfma_k(const float *__restrict__ g, const float *__restrict__ y, int relu_mode,
             float inv_keep, const float *__restrict__ agg, const float *__restrict__ x, int64_t M,
-            int Fi, float *__restrict__ slabs) {
+            int Fi, int Fo, float *__restrict__ slabs) {
+  // blockIdx.y selects a block of 64 output columns (Fo = 64, 128, 256 ...)
+  g += blockIdx.y * 64;
+  y += blockIdx.y * 64;
   __shared__ float red[4][17][64];
   const int lane = gs_lane(), wave = threadIdx.x >> 6;
   const int slot = lane >> 4, sub = lane & 15;
@@ -798,8 +802,8 @@ dw16_mfma_k(const float *__restrict__ g, const float *__restrict__ y, int relu_m
     for (int u = 0; u < U; ++u) {
       int64_t row = r0 + u * 4 + slot;
       bool live = row < M;
-      d[u] = live ? *(const float4 *)(g + row * 64 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      yv[u] = (live && relu_mode) ? *(const float4 *)(y + row * 64 + sub * 4)
+      d[u] = live ? *(const float4 *)(g + row * Fo + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      yv[u] = (live && relu_mode) ? *(const float4 *)(y + row * Fo + sub * 4)
                                   : make_float4(1.f, 1.f, 1.f, 1.f);
       float av = 0.f;
       if (live) {
@@ -833,7 +837,7 @@ dw16_mfma_k(const float *__restrict__ g, const float *__restrict__ y, int relu_m
     for (int r = 0; r < 4; ++r) red[wave][c * 4 + r][lane] = acc[c][r];
   red[wave][16][lane] = slot == 0 ? bacc.x : slot == 1 ? bacc.y : slot == 2 ? bacc.z : bacc.w;
   __syncthreads();
-  float *slab = slabs + (int64_t)blockIdx.x * DW16_SLAB;
+  float *slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * DW16_SLAB;
   for (int e = threadIdx.x; e < 17 * 64; e += 256) {
     int q = e >> 6, l = e & 63;
     float v = red[0][q][l] + red[1][q][l] + red[2][q][l] + red[3][q][l];
@@ -854,6 +858,7 @@ reduce_dw16_k(const float *__restrict__ slabs, int nslab, int Fi, float *__restr
   __shared__ float red[4][64];
   const int lane = gs_lane(), wave = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
+  slabs += (int64_t)blockIdx.y * nslab * DW16_SLAB;   // this block of 64 output columns
   float s = 0.f;
   if (e < DW16_SLAB)
     for (int b = wave; b < nslab; b += 4) s += slabs[(int64_t)b * DW16_SLAB + e];
@@ -862,11 +867,11 @@ reduce_dw16_k(const float *__restrict__ slabs, int nslab, int Fi, float *__restr
   if (wave == 0 && e < DW16_SLAB) {
     float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
     if (e < 64 * 16) {
-      int m = e >> 4, k = e & 15;
+      int m = blockIdx.y * 64 + (e >> 4), k = e & 15;
       if (k < 8) { if (k < Fi) gwl[m * Fi + k] = v; }
       else if (k - 8 < Fi) gwr[m * Fi + k - 8] = v;
     } else {
-      gb[e - 64 * 16] = v;
+      gb[blockIdx.y * 64 + e - 64 * 16] = v;
     }
   }
 }
@@ -896,21 +901,30 @@ dw_generic_k(const float *__restrict__ dpre, const float *__restrict__ agg,
   }
 }
 
-// sum the slabs in order and split into grad_W_l, grad_W_r, grad_b
-__global__ void reduce_slabs_k(const float *__restrict__ slabs, int nslab, int Fi, int Fo,
-                               float *__restrict__ gwl, float *__restrict__ gwr,
-                               float *__restrict__ gb) {
+// sum the slabs and split into grad_W_l, grad_W_r, grad_b.  lane = output element (coalesced
+// over a slab's inner index); the 4 waves take slabs w, w+4, ... and combine through LDS in
+// wave order: a fixed order, so the result is bitwise reproducible.
+__global__ void __launch_bounds__(256)
+reduce_slabs_k(const float *__restrict__ slabs, int nslab, int Fi, int Fo,
+               float *__restrict__ gwl, float *__restrict__ gwr, float *__restrict__ gb) {
+  __shared__ float red[4][64];
+  const int lane = gs_lane(), wave = threadIdx.x >> 6;
   const int K2 = 2 * Fi;
   const int total = Fo * K2 + Fo;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int b = 0; b < nslab; ++b) s += slabs[(int64_t)b * total + e];
+  const int e = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (e < total)
+    for (int b = wave; b < nslab; b += 4) s += slabs[(int64_t)b * total + e];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && e < total) {
+    float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
     if (e < Fo * K2) {
       int m = e / K2, k = e % K2;
-      if (k < Fi) gwl[m * Fi + k] = s;
-      else gwr[m * Fi + k - Fi] = s;
+      if (k < Fi) gwl[m * Fi + k] = v;
+      else gwr[m * Fi + k - Fi] = v;
     } else {
-      gb[e - Fo * K2] = s;
+      gb[e - Fo * K2] = v;
     }
   }
 }
@@ -974,9 +988,9 @@ extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *
   }
   hipLaunchKernelGGL(pack_t_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
   int grid = gs_grid(N, 4, 256 * 16);
-  if (2 * Fi <= 16 && Fo <= 64)
-    hipLaunchKernelGGL((project_fwd_smallk_k<16>), dim3(grid), dim3(256), 0, st, agg, x, wp, N, fi,
-                       fo, e, out);
+  if (2 * Fi <= 16 && (Fo <= 64 || (Fo % 64 == 0 && epilogue != GSAGE_EPI_L2NORM)))
+    hipLaunchKernelGGL((project_fwd_smallk_k<16>), dim3(grid, (fo + 63) / 64), dim3(256), 0, st, agg,
+                       x, wp, N, fi, fo, e, out);
   else
     hipLaunchKernelGGL(project_fwd_generic_k, dim3(grid), dim3(256), 0, st, agg, x, wp, N, fi, fo,
                        e, out);
@@ -988,7 +1002,7 @@ extern "C" size_t gsage_project_bwd_workspace_bytes(int64_t N, int64_t Fi, int64
   if (N < 0 || Fi <= 0 || Fo <= 0) return 0;
   size_t pack = gs_align_up((size_t)(2 * Fi * Fo) * sizeof(float), 256);
   size_t slabs = gs_align_up((size_t)num_slabs(N) * (size_t)(2 * Fi * Fo + Fo) * sizeof(float), 256);
-  size_t slabs16 = (Fo == 64 && Fi <= 8) ? (size_t)DW16_BLOCKS * DW16_SLAB * sizeof(float) : 0;
+  size_t slabs16 = (Fo % 64 == 0 && Fi <= 8) ? (size_t)DW16_BLOCKS * DW16_SLAB * sizeof(float) : 0;
   return pack + (slabs > slabs16 ? slabs : slabs16);
 }
 
@@ -1033,7 +1047,7 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
       hipLaunchKernelGGL(bwd64_fused_k, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x,
                          wp, agg_scale, N, epilogue, ik, grad_agg, grad_x, slabs);
       GSAGE_CHECK_LAUNCH();
-      hipLaunchKernelGGL(reduce_slabs_k, dim3(gs_grid(2 * Fi * Fo + Fo, 256, 256)), dim3(256), 0,
+      hipLaunchKernelGGL(reduce_slabs_k, dim3((unsigned)((2 * Fi * Fo + Fo + 63) / 64)), dim3(256), 0,
                          st, slabs, grid, fi, fo, grad_w_l, grad_w_r, grad_b);
       GSAGE_CHECK_LAUNCH();
       return GSAGE_OK;
@@ -1043,7 +1057,7 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
   // 1. dpre
   const float *dp = grad_out;
   const float inv_keep = epilogue == GSAGE_EPI_RELU_DROPOUT ? 1.0f / (1.0f - p) : 1.0f;
-  const bool smallk = 2 * Fi <= 16 && Fo <= 64;
+  const bool smallk = 2 * Fi <= 16 && (Fo <= 64 || Fo % 64 == 0);
   const bool relu_epi = epilogue == GSAGE_EPI_RELU || epilogue == GSAGE_EPI_RELU_DROPOUT;
   // first layer in training: no input gradient wanted -> the ReLU derivative is applied
   // inside the dW kernel and dpre is never materialised
@@ -1078,13 +1092,15 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
   }
 
   // 3. weight gradients: partial slabs, then an ordered sum
-  if (force_generic == 0 && Fo == 64 && Fi <= 8 && ((((uintptr_t)dp | (uintptr_t)out) & 15) == 0)) {
-    int grid = gs_grid(N, 64, DW16_BLOCKS);
-    hipLaunchKernelGGL(dw16_mfma_k, dim3(grid), dim3(256), 0, st, dp, out, fuse_relu ? 1 : 0,
-                       inv_keep, agg, x, N, fi, slabs);
+  if (force_generic == 0 && Fo % 64 == 0 && Fi <= 8 &&
+      ((((uintptr_t)dp | (uintptr_t)out) & 15) == 0)) {
+    int ncb = fo / 64;
+    int grid = gs_grid(N, 64, DW16_BLOCKS / ncb);
+    hipLaunchKernelGGL(dw16_mfma_k, dim3(grid, ncb), dim3(256), 0, st, dp, out, fuse_relu ? 1 : 0,
+                       inv_keep, agg, x, N, fi, fo, slabs);
     GSAGE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_dw16_k, dim3((DW16_SLAB + 63) / 64), dim3(256), 0, st, slabs, grid, fi,
-                       grad_w_l, grad_w_r, grad_b);
+    hipLaunchKernelGGL(reduce_dw16_k, dim3((DW16_SLAB + 63) / 64, ncb), dim3(256), 0, st, slabs,
+                       grid, fi, grad_w_l, grad_w_r, grad_b);
     GSAGE_CHECK_LAUNCH();
     return GSAGE_OK;
   }
@@ -1093,7 +1109,7 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
   if (mfma) {
     dim3 grid((unsigned)nslab, (unsigned)((fo / 64) * (2 * fi / 128)));
     hipLaunchKernelGGL(dw_mfma_k, grid, dim3(256), 0, st, dp, agg, x, N, fi, fo, rpb, slabs);
-  } else if (smallk) {
+  } else if (2 * Fi <= 16 && Fo <= 64) {
     hipLaunchKernelGGL((dw_smallk_k<16>), dim3(nslab), dim3(256), 0, st, dp, out, fuse_relu ? 1 : 0,
                        inv_keep, agg, x, N, fi, fo, rpb, slabs);
   } else {
@@ -1101,7 +1117,7 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
                        slabs);
   }
   GSAGE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_slabs_k, dim3(gs_grid(2 * Fi * Fo + Fo, 256, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(reduce_slabs_k, dim3((unsigned)((2 * Fi * Fo + Fo + 63) / 64)), dim3(256), 0, st,
                      slabs, nslab, fi, fo, grad_w_l, grad_w_r, grad_b);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;

@@ -38,7 +38,7 @@ def _case(n, fi, fo, seed):
 
 
 SHAPES = [(7, 64), (64, 64), (64, 128), (128, 128), (128, 64), (256, 256), (7, 32), (32, 32),
-          (5, 3), (64, 96), (20, 64), (7, 100)]
+          (5, 3), (64, 96), (20, 64), (7, 100), (8, 128), (7, 256), (8, 64)]
 
 
 @pytest.mark.parametrize("epi", EPIS)
