@@ -38,6 +38,25 @@ def log(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def measured_traffic(workload, F):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_hbm.json: separate FETCH_SIZE and WRITE_SIZE runs of this same command).
+    gfx950 correction: FETCH_SIZE counts 128-B read requests as 64 B, so it is doubled."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_hbm.json"))):
+        best = path
+    if best is None:
+        return None, None
+    try:
+        z = json.load(open(best))
+        k = f"seg_gather_vec_k<{F // 4}, false>"
+        fetch_kb, write_kb = z["FETCH_SIZE"][k]["mean_KB"], z["WRITE_SIZE"][k]["mean_KB"]
+        return (2.0 * fetch_kb + write_kb) * 1024.0, os.path.relpath(best, ROOT)
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def cpu_baseline(args, hidden, out_dim, K):
     """The CPU oracle (oracle/sage_oracle.py: the op sequence PyG + loss.py execute on CPU,
     plus clip + Adam) on a bounded sample: the same generator at `--cpu-nodes` nodes with the
@@ -81,7 +100,7 @@ def main():
     ap.add_argument("--negatives", type=int, default=5)
     ap.add_argument("--dropout", type=float, default=0.3)
     ap.add_argument("--cpu-nodes", type=int, default=200_000)
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -153,9 +172,10 @@ def main():
     launches, mean_ms = timer.summary().get(f"segment_gather_F{F}", (0, float("nan")))
     alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if launches else float("nan")
-    roofline = {"bound": "hbm", "kernel": f"seg_gather_vec_k<{F // 4}> (+hub pass), F={F}",
+    traffic, traffic_src = measured_traffic(args.workload, F)
+    roofline = {"bound": "hbm", "kernel": f"seg_gather_vec_k<{F // 4},false> (hub rows included), F={F}",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches_timed": launches, "mean_ms": mean_ms, "algorithmic_bytes": alg_bytes}
 
     if rank == 0:

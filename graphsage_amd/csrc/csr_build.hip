@@ -328,6 +328,10 @@ extern "C" int gsage_csr_build(const int64_t *edge_index, int64_t E, int64_t N, 
     return GSAGE_ERR_INVALID_ARG;
   if (E > 0 && (!edge_index || !col || !col_t)) return GSAGE_ERR_INVALID_ARG;
   if (E >= (1ll << 31) - 1 || N >= (1ll << 31) - 2) return GSAGE_ERR_UNSUPPORTED;
+  // at most E / threshold rows can be longer than the threshold: a smaller list could be
+  // truncated, and the gather kernels would then skip rows nobody owns
+  if ((long_rows || long_rows_t) && (!n_long || long_cap < E / LONG_ROW_T + 1))
+    return GSAGE_ERR_INVALID_ARG;
   CsrWsLayout L = csr_layout(E, N);
   if (ws_bytes < L.total) return GSAGE_ERR_WORKSPACE;
   hipStream_t st = gs_stream(stream);

@@ -64,7 +64,7 @@ const char *gsage_error_string(int status);
  *   rowptr_t[N+1], col_t[E] : the transpose (grouped by source, col_t = targets)
  *   inv_deg[N]              : 1.0f / max(in_degree, 1)
  *   long_rows / long_rows_t : ids of rows with more than gsage_long_row_threshold()
- *                             entries (capacity `long_cap` each); n_long[0] and
+ *                             entries (capacity `long_cap` >= E/threshold + 1 each); n_long[0] and
  *                             n_long[1] receive their counts (for the hub-row pass of
  *                             the aggregation kernels).  May be NULL (then skipped).
  *   status                  : int32[1], OR-ed with GSAGE_FLAG_INDEX_OUT_OF_RANGE when an

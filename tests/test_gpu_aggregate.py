@@ -99,3 +99,30 @@ def test_bitwise_reproducible_and_linear_at_c2_size():
     ref = O.mean_aggregate(x.cpu(), ei.cpu())
     assert_close(a1.cpu(), ref)
 
+
+
+def test_full_size_c4_conservation_identities():
+    """BASELINE size (10M nodes / ~200M edges): checks that need no oracle.
+      sum_i deg_in(i) * mean_agg(x)[i]  ==  sum_j deg_out(j) * x[j]     (every edge counted once)
+      transposed sum-gather of ones     ==  out-degree
+    and the CSR invariants rowptr[N] == E, rowptr monotone, col within range."""
+    from graphsage_amd.graph import build_csr
+    from graphsage_amd.ops import aggregate_mean, aggregate_mean_bwd
+    from graphsage_amd.synth import powerlaw_graph
+    n = 10_000_000
+    ei = powerlaw_graph(n, 20, seed=42, device="cuda")
+    E = ei.size(1)
+    g = build_csr(ei, n)
+    assert int(g.rowptr[-1]) == E and int(g.rowptr_t[-1]) == E
+    assert bool((g.rowptr[1:] >= g.rowptr[:-1]).all())
+    assert int(g.col.min()) >= 0 and int(g.col.max()) < n
+    assert torch.equal(g.col_t.to(torch.int64), ei[1])            # input is sorted by source
+    x = torch.rand(n, 64, device="cuda")
+    agg = aggregate_mean(g, x)
+    lhs = (agg.double() * g.in_degree()[:, None]).sum(0)
+    rhs = (x.double() * g.out_degree()[:, None]).sum(0)
+    assert torch.allclose(lhs, rhs, rtol=1e-6)
+    ones = torch.ones(n, 64, device="cuda")
+    outdeg = aggregate_mean_bwd(g, ones, prescaled=True)
+    assert torch.equal(outdeg[:, 0].to(torch.int64), g.out_degree())
+    assert torch.equal(aggregate_mean(g, x), agg)                  # bitwise reproducible
