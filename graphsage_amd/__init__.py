@@ -5,7 +5,11 @@ from .graphsage import GraphSAGE, SAGEConv, create_model
 from .loss import SkipGramLoss, create_loss
 from .graph import GraphCSR, GraphCache, build_csr, default_cache
 from .train_step import TrainStep, FlatParams, shard_bounds
+from .sampler import DegreeBiasedNegativeSampler, UniformNegativeSampler
+from .trainer import GraphSAGETrainer, BatchGenerator, Batch, split_pairs_train_val
 
 __all__ = ["GraphSAGE", "SAGEConv", "create_model", "SkipGramLoss", "create_loss", "GraphCSR",
-           "GraphCache", "build_csr", "default_cache", "TrainStep", "FlatParams", "shard_bounds"]
+           "GraphCache", "build_csr", "default_cache", "TrainStep", "FlatParams", "shard_bounds", "DegreeBiasedNegativeSampler",
+           "UniformNegativeSampler", "GraphSAGETrainer", "BatchGenerator", "Batch",
+           "split_pairs_train_val"]
 __version__ = "0.1.0"

@@ -43,6 +43,7 @@ SIGNATURES = {
     "gsage_skipgram_fwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, C.c_float,
                                      C.c_double, C.c_double, _p, _p, _p, _sz, _p]),
     "gsage_skipgram_bwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
+    "gsage_alias_build_host": (C.c_int, [_p, _i64, _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -67,8 +67,13 @@ class TrainStep:
         self.gradient_clip = gradient_clip
         self.loss_fn = loss_fn if loss_fn is not None else SkipGramLoss(scale_factor)
         self.flat = FlatParams(model)
+        # capturable: the step counter lives on the device, so the optimiser can sit inside a
+        # captured HIP graph (capture_step below) as well as run eagerly
+        on_gpu = self.flat.flat.is_cuda
         self.optimizer = torch.optim.Adam([self.flat.flat_param], lr=learning_rate,
-                                          weight_decay=weight_decay)
+                                          weight_decay=weight_decay, capturable=on_gpu,
+                                          foreach=False if not on_gpu else None)
+        self._graph = None
         self.distributed = dist.is_available() and dist.is_initialized()
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
@@ -94,6 +99,102 @@ class TrainStep:
             torch.nn.utils.clip_grad_norm_([self.flat.flat_param], self.gradient_clip)
         self.optimizer.step()
         return self.flat.extra
+
+    # ------------------------------------------------------------- whole step as one HIP graph
+    def capture_step(self, batch_size: int, num_negatives: int, warmup: int = 3) -> None:
+        """Capture zero_grad -> forward -> loss -> backward -> clip -> Adam into ONE HIP graph
+        for batches of exactly (batch_size, num_negatives).  Worth it when the graph is small
+        and the step is launch-bound (the reference's default B = 1024 on its 500-node graph:
+        ~60 launches of a few microseconds each).  Dropout masks are then drawn by torch's
+        graph-safe Philox generator and handed to the projection kernel as keep-masks (a seed
+        passed by value would be frozen into the graph)."""
+        if self.world > 1:
+            raise RuntimeError("capture_step covers the single-GPU step only")
+        dev = self.features.device
+        self._gt = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self._gc = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self._gn = torch.zeros(batch_size, num_negatives, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):          # builds the CSR cache, sets kernel attributes
+                self._graph_body(batch_size)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        # the warm-up steps above moved the parameters: that is the caller's to know
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_body(batch_size)
+
+    def _graph_body(self, batch_size: int) -> None:
+        model = self.model
+        model.train()
+        self.flat.zero_grad()
+        masks = None
+        p = float(getattr(model, "dropout_rate", 0.0))
+        if p > 0.0:
+            n = self.features.size(0)
+            masks = [(torch.rand(n, conv.out_channels, device=self.features.device) >= p)
+                     .to(torch.uint8) for conv in model.convs[:-1]]
+        emb = model(self.features, self.edge_index, keep_masks=masks)
+        loss, stats = self.loss_fn.forward_stats(emb, self._gt, self._gc, self._gn,
+                                                 global_batch=batch_size)
+        loss.backward()
+        self.flat.extra.copy_(stats)
+        if self.gradient_clip > 0:
+            torch.nn.utils.clip_grad_norm_([self.flat.flat_param], self.gradient_clip)
+        self.optimizer.step()
+
+    def step_captured(self, targets, contexts, negatives) -> torch.Tensor:
+        """Replay the captured step on a new batch (copied into the graph's static inputs)."""
+        if self._graph is None:
+            raise RuntimeError("call capture_step() first")
+        self._gt.copy_(targets)
+        self._gc.copy_(contexts)
+        self._gn.copy_(negatives)
+        self._graph.replay()
+        return self.flat.extra
+
+    # ----------------------------------------------- optimiser state in the reference's layout
+    def optimizer_state_dict(self) -> dict:
+        """Adam state as ``Adam(model.parameters())`` of the reference would hold it (one entry
+        per parameter tensor), so ``optimizer_state_dict`` in checkpoints stays interchangeable
+        (``trainer.py:385-391``, ``callbacks.py:220-233``)."""
+        st = self.optimizer.state.get(self.flat.flat_param, {})
+        group = {k: v for k, v in self.optimizer.param_groups[0].items() if k != "params"}
+        state, off = {}, 0
+        for i, p in enumerate(self.flat.params):
+            k = p.numel()
+            if st:
+                state[i] = {"step": st["step"].detach().clone().cpu().to(torch.float32),
+                            "exp_avg": st["exp_avg"][off:off + k].view_as(p).clone(),
+                            "exp_avg_sq": st["exp_avg_sq"][off:off + k].view_as(p).clone()}
+            off += k
+        group["params"] = list(range(len(self.flat.params)))
+        group["capturable"] = False      # a property of this harness, not of the checkpoint
+        group["foreach"] = None
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        if not sd.get("state"):
+            return
+        fp = self.flat.flat_param
+        exp_avg, exp_avg_sq = torch.zeros_like(fp.data), torch.zeros_like(fp.data)
+        off, step = 0, None
+        for i, p in enumerate(self.flat.params):
+            k = p.numel()
+            ent = sd["state"][i]
+            exp_avg[off:off + k].copy_(ent["exp_avg"].reshape(-1))
+            exp_avg_sq[off:off + k].copy_(ent["exp_avg_sq"].reshape(-1))
+            step = ent["step"]
+            off += k
+        step_t = torch.as_tensor(float(step), dtype=torch.float32,
+                                 device=fp.device if self.optimizer.defaults.get("capturable") else "cpu")
+        self.optimizer.state[fp] = {"step": step_t, "exp_avg": exp_avg, "exp_avg_sq": exp_avg_sq}
+        g = sd["param_groups"][0]
+        for key in ("lr", "betas", "eps", "weight_decay"):
+            if key in g:
+                self.optimizer.param_groups[0][key] = g[key]
 
     def step_with_details(self, targets, contexts, negatives,
                           global_batch: Optional[int] = None) -> Dict[str, float]:

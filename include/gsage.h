@@ -168,6 +168,16 @@ int gsage_skipgram_bwd(const float *emb, int64_t N, int64_t D, const int64_t *ta
                        int64_t K, const float *coef, const float *grad_loss,
                        float *grad_emb, gsage_stream_t stream);
 
+/* ------------------------------------------- feeder: alias table (HOST pointers, host code)
+ * Replaces the interpreter loop of DegreeBiasedNegativeSampler._setup_alias_table
+ * (src/walks/negative_sampler.py:95-145).  scaled_probs[i] = probs[i] * n (float32).
+ * Sequential Vose construction in the reference's exact order (ascending fill, LIFO use,
+ * float32 updates) => prob_table / alias are bit-identical to the reference's.
+ * All three pointers are HOST memory; no GPU is touched.
+ */
+int gsage_alias_build_host(const float *scaled_probs, int64_t n, float *prob_table,
+                           int64_t *alias);
+
 #ifdef __cplusplus
 }
 #endif

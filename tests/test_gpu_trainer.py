@@ -1,0 +1,153 @@
+"""GPU: training harness: epoch means vs the oracle on injected batches, the
+captured-HIP-graph step vs the eager step, checkpoints interchangeable with plain torch Adam."""
+import os
+
+import pytest
+import torch
+
+from oracle import sage_oracle as O
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+class FixedNegatives:
+    """Sampler stub handing out pre-drawn negatives in order (so both sides see the same)."""
+
+    def __init__(self, negs):
+        self.negs, self.i = negs, 0
+
+    def sample(self, b, k):
+        out = self.negs[self.i][:b, :k]
+        self.i += 1
+        return out
+
+    def to(self, device):
+        self.negs = [n.to(device) for n in self.negs]
+        return self
+
+
+def _setup(n=1500, pairs=2500, hidden=64, dropout=0.0, seed=0):
+    from graphsage_amd import GraphSAGE
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    ei = powerlaw_graph(n, 10, seed=42)
+    x = memory_features(n, seed=42)
+    t, c, _ = cooccurrence_batch(ei, n, pairs, 5, seed=7)
+    torch.manual_seed(seed)
+    ref = O.OracleGraphSAGE(7, hidden, hidden, 2, dropout)
+    m = GraphSAGE(7, hidden, hidden, 2, dropout)
+    m.load_state_dict(ref.state_dict())
+    return n, ei, x, t, c, m.cuda(), ref
+
+
+def test_epoch_means_match_oracle_on_injected_batches():
+    from graphsage_amd import GraphSAGETrainer
+    n, ei, x, t, c, m, ref = _setup()
+    bs = 1024
+    g = torch.Generator().manual_seed(1)
+    negs = [torch.randint(0, n, (2 * bs, 5), generator=g) for _ in range(8)]
+    cfg = {"training": {"batch_size": bs, "learning_rate": 1e-3, "gradient_clip": 1.0},
+           "negatives": {"per_positive": 5}, "validation": {"val_fraction": 0.0}}
+    tr = GraphSAGETrainer(m, x.cuda(), ei.cuda(), (t, c), FixedNegatives(list(negs)), cfg)
+    tr.batch_generator.shuffle = False
+    assert len(tr.batch_generator) == 3                       # 1024, 1024, 452 (drop_last=False)
+    metrics = tr.train_epoch()
+    opt = O.make_adam(ref)
+    ref.train()
+    acc = {"loss": 0.0, "pos_loss": 0.0, "neg_loss": 0.0}
+    for i, lo in enumerate(range(0, t.numel(), bs)):
+        hi = min(lo + bs, t.numel())
+        _, d = O.train_step(ref, opt, x, ei, t[lo:hi], c[lo:hi], negs[i][:hi - lo])
+        acc["loss"] += d["total_loss"]; acc["pos_loss"] += d["pos_loss"]; acc["neg_loss"] += d["neg_loss"]
+    for k in acc:
+        assert metrics[k] == pytest.approx(acc[k] / 3, rel=2e-5), k
+    for (name, pg), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(pg, pr, rtol=1e-4, floor=2e-5, what=name)
+
+
+def test_validate_and_train_loop_and_checkpoint(tmp_path):
+    from graphsage_amd import DegreeBiasedNegativeSampler, GraphSAGE, GraphSAGETrainer
+    n, ei, x, t, c, m, ref = _setup(dropout=0.3)
+    cfg = {"training": {"batch_size": 512, "early_stopping_patience": 50},
+           "negatives": {"per_positive": 5}, "validation": {"val_fraction": 0.1},
+           "paths": {"checkpoints": str(tmp_path / "ck")}}
+    sampler = DegreeBiasedNegativeSampler(ei, n)
+    tr = GraphSAGETrainer(m, x.cuda(), ei.cuda(), list(zip(t.tolist(), c.tolist())), sampler, cfg)
+    assert tr.train_pairs[0].numel() == 2250 and tr.val_pairs[0].numel() == 250
+    v0 = tr.validate()
+    assert set(v0) == {"loss", "pos_prob", "neg_prob"} and 0 < v0["loss"] < 10
+    best = tr.train(num_epochs=6)
+    assert best < v0["loss"] and 0 < best < 10                   # tests/test_integration.py:93-157
+    assert tr.get_embeddings().shape == (n, 64)
+    ck = torch.load(tmp_path / "ck" / "model_best.pt", weights_only=True)
+    assert {"epoch", "model_state_dict", "optimizer_state_dict", "best_loss", "config"} <= set(ck)
+    # the reference's loaders accept it: strict model load + a plain per-parameter Adam
+    ref.load_state_dict(ck["model_state_dict"], strict=True)
+    opt = O.make_adam(ref)
+    opt.load_state_dict(ck["optimizer_state_dict"])
+    assert len(opt.state_dict()["state"]) == 6
+    m2 = GraphSAGE(7, 64, 64, 2, 0.3).cuda()
+    tr2 = GraphSAGETrainer(m2, x.cuda(), ei.cuda(), (t, c), sampler, cfg)
+    tr2.load_checkpoint(str(tmp_path / "ck" / "model_best.pt"))
+    for pa, pb in zip(m2.state_dict().values(), ck["model_state_dict"].values()):
+        assert torch.equal(pa.cpu(), pb.cpu())
+
+
+def test_resume_from_exported_optimizer_state_continues_identically():
+    """Adam moments exported per parameter -> torch Adam on the oracle continues in step."""
+    from graphsage_amd import TrainStep
+    from graphsage_amd.synth import cooccurrence_batch
+    n, ei, x, t, c, m, ref = _setup()
+    ts = TrainStep(m, x.cuda(), ei.cuda())
+    batches = [cooccurrence_batch(ei, n, 512, 5, seed=s) for s in range(4)]
+    for b in batches[:2]:
+        ts.step(*[v.cuda() for v in b])
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    opt = O.make_adam(ref)
+    opt.load_state_dict(ts.optimizer_state_dict())
+    ref.train()
+    for b in batches[2:]:
+        ts.step(*[v.cuda() for v in b])
+        O.train_step(ref, opt, x, ei, *b)
+    for (name, pg), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(pg, pr, rtol=1e-4, floor=2e-5, what=name)
+
+
+def test_captured_step_matches_eager_step():
+    from graphsage_amd import GraphSAGE, TrainStep
+    from graphsage_amd.synth import cooccurrence_batch
+    n, ei, x, t, c, m, ref = _setup(n=500, pairs=10)
+    m2 = GraphSAGE(7, 64, 64, 2, 0.0).cuda()
+    m2.load_state_dict(m.state_dict())
+    snap = {k: v.clone() for k, v in m.state_dict().items()}
+    eager = TrainStep(m, x.cuda(), ei.cuda())
+    graph = TrainStep(m2, x.cuda(), ei.cuda())
+    graph.capture_step(batch_size=256, num_negatives=5, warmup=1)
+    # warm-up and capture ran real steps (on all-zero pairs): rewind the captured side's
+    # parameters and Adam state to the common start
+    m2.load_state_dict(snap)
+    st = graph.optimizer.state[graph.flat.flat_param]
+    st["step"].zero_(), st["exp_avg"].zero_(), st["exp_avg_sq"].zero_()
+    for s in range(4):
+        b = [v.cuda() for v in cooccurrence_batch(ei, n, 256, 5, seed=20 + s)]
+        se = eager.step(*b).clone()
+        sg = graph.step_captured(*b).clone()
+        assert_close(sg[:7], se[:7], rtol=2e-5, floor=1e-6, what=f"stats step {s}")
+    for (name, pa), (_, pb) in zip(m.named_parameters(), m2.named_parameters()):
+        assert_close(pb, pa, rtol=1e-4, floor=2e-5, what=name)
+
+
+def test_captured_step_with_dropout_draws_new_masks_each_replay():
+    from graphsage_amd import GraphSAGE, TrainStep
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    n = 800
+    ei = powerlaw_graph(n, 10, seed=42).cuda()
+    x = memory_features(n, seed=42).cuda()
+    torch.manual_seed(0)
+    m = GraphSAGE(7, 64, 64, 2, 0.5).cuda()
+    ts = TrainStep(m, x, ei, learning_rate=0.0)                 # lr 0: only the mask changes
+    ts.capture_step(128, 5, warmup=1)
+    b = [v for v in cooccurrence_batch(ei, n, 128, 5, seed=3)]
+    l1 = ts.step_captured(*b)[0].item()
+    l2 = ts.step_captured(*b)[0].item()
+    assert l1 != l2 and abs(l1 - l2) < 1.0
