@@ -6,10 +6,11 @@ from .loss import SkipGramLoss, create_loss
 from .graph import GraphCSR, GraphCache, build_csr, default_cache
 from .train_step import TrainStep, FlatParams, shard_bounds
 from .sampler import DegreeBiasedNegativeSampler, UniformNegativeSampler
+from .encoder import StructuralEncoder, model_from_checkpoint
 from .trainer import GraphSAGETrainer, BatchGenerator, Batch, split_pairs_train_val
 
 __all__ = ["GraphSAGE", "SAGEConv", "create_model", "SkipGramLoss", "create_loss", "GraphCSR",
            "GraphCache", "build_csr", "default_cache", "TrainStep", "FlatParams", "shard_bounds", "DegreeBiasedNegativeSampler",
            "UniformNegativeSampler", "GraphSAGETrainer", "BatchGenerator", "Batch",
-           "split_pairs_train_val"]
+           "split_pairs_train_val", "StructuralEncoder", "model_from_checkpoint"]
 __version__ = "0.1.0"
