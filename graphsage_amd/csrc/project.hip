@@ -90,6 +90,10 @@ struct GemmArgs {
 constexpr int G_BK = 32;
 constexpr int G_PITCH = G_BK + 4;
 
+__device__ __forceinline__ float f4c(const float4 &v, int s) {
+  return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w;
+}
+
 constexpr int MODE_DX = 100;  // epilogue of the dX GEMM (scale dest 1 rows, no bias)
 
 template <int WM, int WN, int TM, int TN>
@@ -261,6 +265,193 @@ int launch_gemm(const GemmArgs &a, hipStream_t st) {
   return GSAGE_OK;
 }
 
+
+// ---- wide layers (128 / 256 columns): 128-row tiles, 8 waves (2 x 4), each wave 64 rows x
+// 32*TN columns.  Twice the rows per weight-tile fetch of gemm_rows_k (the 256-wide layer was
+// bound by re-reading W from L2 per 64-row tile), and the epilogue works straight on the
+// accumulators (row norms by lane shuffles + a 2 KiB LDS exchange between the 4 column waves),
+// so no 128 x 256 output tile has to fit in LDS.
+template <int TN>
+__global__ void __launch_bounds__(512, 4) gemm_wide_k(GemmArgs a) {
+  constexpr int BM = 128, BN = 128 * TN, TM = 2;
+  constexpr int NA = BM * 8 / 512, NB = BN * 8 / 512;
+  constexpr int STAGE = (BM + BN) * G_PITCH;             // floats per LDS stage (A then B)
+  extern __shared__ __align__(16) float wide_smem[];     // one stage + rowss
+  float (*rowss)[4] = (float (*)[4])(wide_smem + 1 * STAGE);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 2, wn = w & 3;
+  const int64_t row0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int K = a.K, K1 = a.K1, K2 = a.K - a.K1;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[NA], rb[NB];
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int f = t + i * 512;
+      int r = f >> 3, c4 = f & 7;
+      int64_t grow = row0 + r;
+      int k = kc + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (grow < a.M) {
+        const float *src = (k < K1) ? a.A1 + grow * K1 + k : a.A2 + grow * K2 + (k - K1);
+        v = *(const float4 *)src;
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int f = t + i * 512;
+      rb[i] = *(const float4 *)(a.Bp + (int64_t)(n0 + (f >> 3)) * K + kc + (f & 7) * 4);
+    }
+  };
+  auto sstore = [&](int stage) {
+    float *As = wide_smem + stage * STAGE, *Bs = As + BM * G_PITCH;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int f = t + i * 512;
+      *(float4 *)(As + (f >> 3) * G_PITCH + (f & 7) * 4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int f = t + i * 512;
+      *(float4 *)(Bs + (f >> 3) * G_PITCH + (f & 7) * 4) = rb[i];
+    }
+  };
+
+  // chunk k+1 travels global -> registers during chunk k's MFMAs.  One LDS stage and two
+  // workgroups per CU measured faster (27.6 ms per 256->256 layer at 10 M rows) than two
+  // stages with one barrier per chunk but a single workgroup per CU (29.0 ms).
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  constexpr int stage = 0;
+  for (int kc = 0; kc < K; kc += G_BK) {
+    const bool more = kc + G_BK < K;
+    if (more) gload(kc + G_BK);
+    const float *As = wide_smem + stage * STAGE, *Bs = As + BM * G_PITCH;
+#pragma unroll
+    for (int g = 0; g < G_BK / 8; ++g) {
+      float4 af[TM], bf[TN];
+      const int koff = g * 8 + (lane >> 5) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *(const float4 *)(As + (wm * 64 + i * 32 + (lane & 31)) * G_PITCH + koff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *(const float4 *)(Bs + ((wn * TN + j) * 32 + (lane & 31)) * G_PITCH + koff);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af[i], s2), f4c(bf[j], s2),
+                                                             acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) sstore(0);
+    __syncthreads();
+  }
+
+  // ---- epilogue on the accumulators: acc[i][j][r] is row wm*64+i*32+(r&3)+8(r>>2)+4(lane>>5),
+  //      column (wn*TN+j)*32 + (lane&31) of the tile
+  const EpiArgs &e = a.epi;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);   // global output column
+    if (e.mode != MODE_DX) {
+      const float b = e.bias[n];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + b;
+          if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) v = fmaxf(v, 0.f);
+          if (e.mode == GSAGE_EPI_RELU_DROPOUT) {
+            int64_t grow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (grow < a.M) {
+              uint64_t idx = (uint64_t)grow * (uint64_t)a.Ncols + (uint64_t)n;
+              bool keep = e.keep_mask ? (e.keep_mask[idx] != 0) : dropout_keep(e.seed, idx, e.p);
+              v = keep ? v * e.inv_keep : 0.f;
+            }
+          }
+          acc[i][j][r] = v;
+        }
+    }
+  }
+  if (e.mode == GSAGE_EPI_L2NORM) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) ss += acc[i][j][r] * acc[i][j][r];
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+        ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 16, 64);
+        if ((lane & 31) == 0)
+          rowss[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][wn] = ss;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float ss = rowss[lr][0] + rowss[lr][1] + rowss[lr][2] + rowss[lr][3];
+        float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j][r] *= rn;
+        if (wn == 0 && (lane & 31) == 0 && e.rnorm && row0 + lr < a.M) e.rnorm[row0 + lr] = rn;
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    const bool second = n >= a.N1;                       // uniform over the wave (N1 % 32 == 0)
+    float *C = second ? a.C2 : a.C1;
+    const int ldc = second ? (a.Ncols - a.N1) : a.N1;
+    const int col = second ? n - a.N1 : n;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int64_t grow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (grow < a.M) {
+          float v = acc[i][j][r];
+          if (e.mode == MODE_DX && !second && e.row_scale) v *= e.row_scale[grow];
+          C[grow * ldc + col] = v;
+        }
+      }
+  }
+}
+
+template <int TN>
+int launch_gemm_wide(const GemmArgs &a, hipStream_t st) {
+  constexpr int BN = 128 * TN;
+  constexpr size_t lds = sizeof(float) * (1 * (128 + BN) * G_PITCH + 128 * 4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)gemm_wide_k<TN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return GSAGE_ERR_LAUNCH;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.Ncols / BN));
+  hipLaunchKernelGGL((gemm_wide_k<TN>), grid, dim3(512), lds, st, a);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}
+
 int launch_gemm_bn(int BN, const GemmArgs &a, hipStream_t st) {
   switch (BN) {
     case 64:  return launch_gemm<2, 2, 1, 1>(a, st);
@@ -363,10 +554,6 @@ dw_mfma_k(const float *__restrict__ dpre, const float *__restrict__ agg,
 // overlap one tile's loads with another's MFMAs.
 constexpr int S64_AP = 132;   // pitch of the [agg | x] tile (128 columns)
 constexpr int S64_DP = 68;    // pitch of a 64-column tile
-
-__device__ __forceinline__ float f4c(const float4 &v, int s) {
-  return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w;
-}
 
 // stage rows [row0, row0+64) of [a1 | a2] (64 columns each) into tile[64][S64_AP]
 __device__ __forceinline__ void s64_stage_cat(const float *__restrict__ a1,
@@ -984,6 +1171,8 @@ extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *
     GemmArgs a{};
     a.A1 = agg; a.A2 = x; a.Bp = wp; a.C1 = out; a.C2 = nullptr;
     a.M = N; a.K1 = fi; a.K = 2 * fi; a.N1 = fo; a.Ncols = fo; a.epi = e;
+    if (force_generic == 0 && fo == 128) return launch_gemm_wide<1>(a, st);
+    if (force_generic == 0 && fo == 256) return launch_gemm_wide<2>(a, st);
     return launch_gemm_bn(fo, a, st);
   }
   hipLaunchKernelGGL(pack_t_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
@@ -1082,7 +1271,8 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
       a.M = N; a.K1 = fo; a.K = fo; a.N1 = fi; a.Ncols = 2 * fi;
       a.epi.mode = MODE_DX;
       a.epi.row_scale = agg_scale;
-      int rc = launch_gemm_bn(fi, a, st);
+      int rc = force_generic != 0 ? launch_gemm_bn(fi, a, st)
+               : (2 * fi == 128 ? launch_gemm_wide<1>(a, st) : launch_gemm_wide<2>(a, st));
       if (rc) return rc;
     } else {
       hipLaunchKernelGGL(dx_generic_k, dim3(gs_grid(N, 4, 256 * 16)), dim3(256), 0, st, dp, w_l,
