@@ -35,7 +35,7 @@ __device__ __forceinline__ float4 group_reduce(float4 a) {
 
 // accumulate neighbours p in [p0, p1) of one row, visiting them in steps of
 // `stride_groups` neighbour slots (this wave owns every slot; hub waves share).
-template <int LPR, bool WEIGHTED>
+template <int LPR, int WMODE>
 __device__ __forceinline__ float4 gather_range(const int *__restrict__ col,
                                                const float *__restrict__ x,
                                                const float *__restrict__ ew, int64_t F,
@@ -63,9 +63,15 @@ __device__ __forceinline__ float4 gather_range(const int *__restrict__ col,
       float4 r1 = v1 ? *(const float4 *)(x + (int64_t)c1 * F + sub * 4) : z;
       float4 r2 = v2 ? *(const float4 *)(x + (int64_t)c2 * F + sub * 4) : z;
       float4 r3 = v3 ? *(const float4 *)(x + (int64_t)c3 * F + sub * 4) : z;
-      if (WEIGHTED) {
-        float w0 = v0 ? ew[c0] : 0.f, w1 = v1 ? ew[c1] : 0.f;
-        float w2 = v2 ? ew[c2] : 0.f, w3 = v3 ? ew[c3] : 0.f;
+      if (WMODE != 0) {
+        float w0, w1, w2, w3;
+        if (WMODE == 1) {          // weight of the source node
+          w0 = v0 ? ew[c0] : 0.f; w1 = v1 ? ew[c1] : 0.f;
+          w2 = v2 ? ew[c2] : 0.f; w3 = v3 ? ew[c3] : 0.f;
+        } else {                   // weight of the edge (same order as col)
+          w0 = v0 ? ew[pc + j0] : 0.f; w1 = v1 ? ew[pc + j1] : 0.f;
+          w2 = v2 ? ew[pc + j2] : 0.f; w3 = v3 ? ew[pc + j3] : 0.f;
+        }
         acc.x += r0.x * w0; acc.y += r0.y * w0; acc.z += r0.z * w0; acc.w += r0.w * w0;
         acc.x += r1.x * w1; acc.y += r1.y * w1; acc.z += r1.z * w1; acc.w += r1.w * w1;
         acc.x += r2.x * w2; acc.y += r2.y * w2; acc.z += r2.z * w2; acc.w += r2.w * w2;
@@ -82,7 +88,7 @@ __device__ __forceinline__ float4 gather_range(const int *__restrict__ col,
       int c = __shfl(cv, j, 64);
       if (j < cnt) {
         float4 r = *(const float4 *)(x + (int64_t)c * F + sub * 4);
-        float w = WEIGHTED ? ew[c] : 1.f;
+        float w = WMODE == 1 ? ew[c] : WMODE == 2 ? ew[pc + j] : 1.f;
         acc.x += r.x * w; acc.y += r.y * w; acc.z += r.z * w; acc.w += r.w * w;
       }
     }
@@ -92,7 +98,7 @@ __device__ __forceinline__ float4 gather_range(const int *__restrict__ col,
 
 // hub rows: one workgroup (4 waves) per row; waves take interleaved 64-neighbour chunks,
 // partial sums are combined through LDS in wave order (fixed => reproducible).
-template <int LPR, bool WEIGHTED>
+template <int LPR, int WMODE>
 __device__ __forceinline__ void hub_rows(const int *__restrict__ rowptr, const int *__restrict__ col,
                                          const float *__restrict__ row_scale,
                                          const float *__restrict__ ew, const float *__restrict__ x,
@@ -110,7 +116,7 @@ __device__ __forceinline__ void hub_rows(const int *__restrict__ rowptr, const i
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int pc = p0 + wave * 64; pc < p1; pc += NW * 64) {
       int pe = pc + 64 < p1 ? pc + 64 : p1;
-      float4 r = gather_range<LPR, WEIGHTED>(col, x, ew, F, pc, pe);
+      float4 r = gather_range<LPR, WMODE>(col, x, ew, F, pc, pe);
       acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
     }
     acc = group_reduce<LPR>(acc);
@@ -137,7 +143,7 @@ __device__ __forceinline__ void hub_rows(const int *__restrict__ rowptr, const i
 }
 
 // ---------------------------------------------------------------- vector path, F = 4*LPR
-template <int LPR, bool WEIGHTED>
+template <int LPR, int WMODE>
 __global__ void __launch_bounds__(AGG_BLOCK)
 seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
                  const float *__restrict__ row_scale, const float *__restrict__ ew,
@@ -145,7 +151,7 @@ seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
                  float *out, int long_t, const int *__restrict__ long_rows,
                  const int *__restrict__ n_long, int hub_blocks) {
   if ((int)blockIdx.x < hub_blocks) {
-    hub_rows<LPR, WEIGHTED>(rowptr, col, row_scale, ew, x, add_to, F, out, long_rows, n_long,
+    hub_rows<LPR, WMODE>(rowptr, col, row_scale, ew, x, add_to, F, out, long_rows, n_long,
                             hub_blocks);
     return;
   }
@@ -165,7 +171,7 @@ seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
       if (row >= N) break;
       int p0 = rowptr[row], p1 = rowptr[row + 1];
       if (long_t > 0 && p1 - p0 > long_t) continue;  // hub pass owns this row
-      float4 acc = gather_range<LPR, WEIGHTED>(col, x, ew, F, p0, p1);
+      float4 acc = gather_range<LPR, WMODE>(col, x, ew, F, p0, p1);
       acc = group_reduce<LPR>(acc);
       if (slot == i) {
         keep = acc;
@@ -190,7 +196,7 @@ seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
 // P = lanes per neighbour slot (power of two >= min(F,64)); each lane owns feature
 // columns sub, sub+P, ... of its slot's neighbour.  Up to 4 columns per lane are kept
 // in registers per sweep (F <= 4*P per sweep; larger F sweeps the row again).
-template <bool WEIGHTED>
+template <int WMODE>
 __global__ void __launch_bounds__(AGG_BLOCK)
 seg_gather_scalar_k(const int *__restrict__ rowptr, const int *__restrict__ col,
                     const float *__restrict__ row_scale, const float *__restrict__ ew,
@@ -217,7 +223,7 @@ seg_gather_scalar_k(const int *__restrict__ rowptr, const int *__restrict__ col,
           int j = st * G + slot;
           int c = __shfl(cv, j, 64);
           if (j < cnt && f < F) {
-            float w = WEIGHTED ? ew[c] : 1.f;
+            float w = WMODE == 1 ? ew[c] : WMODE == 2 ? ew[pc + j] : 1.f;
             acc += x[(int64_t)c * F + f] * w;
           }
         }
@@ -235,18 +241,22 @@ seg_gather_scalar_k(const int *__restrict__ rowptr, const int *__restrict__ col,
 template <int LPR>
 int launch_vec(const int *rowptr, const int *col, const float *row_scale, const float *ew,
                const float *x, const float *add_to, int64_t N, int64_t F, float *out,
-               const int *long_rows, const int *n_long, hipStream_t st) {
+               const int *long_rows, const int *n_long, hipStream_t st, bool per_edge = false) {
   constexpr int G = 64 / LPR;
   const bool hubs = long_rows && n_long;
   const int long_t = hubs ? gsage_long_row_threshold() : 0;
   const int hub_blocks = hubs ? HUB_BLOCKS : 0;
   const int grid = gs_grid(N, (AGG_BLOCK / 64) * G, 256 * 64) + hub_blocks;
-  if (ew)
-    hipLaunchKernelGGL((seg_gather_vec_k<LPR, true>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
+  if (ew && per_edge)
+    hipLaunchKernelGGL((seg_gather_vec_k<LPR, 2>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
+                       col, row_scale, ew, x, add_to, N, F, out, long_t, long_rows, n_long,
+                       hub_blocks);
+  else if (ew)
+    hipLaunchKernelGGL((seg_gather_vec_k<LPR, 1>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
                        col, row_scale, ew, x, add_to, N, F, out, long_t, long_rows, n_long,
                        hub_blocks);
   else
-    hipLaunchKernelGGL((seg_gather_vec_k<LPR, false>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
+    hipLaunchKernelGGL((seg_gather_vec_k<LPR, 0>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
                        col, row_scale, ew, x, add_to, N, F, out, long_t, long_rows, n_long,
                        hub_blocks);
   GSAGE_CHECK_LAUNCH();
@@ -255,36 +265,57 @@ int launch_vec(const int *rowptr, const int *col, const float *row_scale, const 
 
 }  // namespace
 
-extern "C" int gsage_segment_gather(const int32_t *rowptr, const int32_t *col,
-                                    const float *row_scale, const float *edge_weight,
-                                    const float *x, const float *add_to, int64_t N, int64_t F,
-                                    float *out, const int32_t *long_rows, const int32_t *n_long,
-                                    gsage_stream_t stream) {
+static int segment_gather_impl(const int32_t *rowptr, const int32_t *col, const float *row_scale,
+                               const float *edge_weight, bool per_edge, const float *x,
+                               const float *add_to, int64_t N, int64_t F, float *out,
+                               const int32_t *long_rows, const int32_t *n_long,
+                               gsage_stream_t stream) {
   if (N < 0 || F <= 0 || !rowptr || !x || !out) return GSAGE_ERR_INVALID_ARG;
   if (N == 0) return GSAGE_OK;
   hipStream_t st = gs_stream(stream);
   bool aligned = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)add_to) & 15) == 0;
   if (aligned) {
     switch (F) {
-      case 4:   return launch_vec<1>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
-      case 8:   return launch_vec<2>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
-      case 16:  return launch_vec<4>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
-      case 32:  return launch_vec<8>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
-      case 64:  return launch_vec<16>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
-      case 128: return launch_vec<32>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
-      case 256: return launch_vec<64>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st);
+      case 4:   return launch_vec<1>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge);
+      case 8:   return launch_vec<2>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge);
+      case 16:  return launch_vec<4>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge);
+      case 32:  return launch_vec<8>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge);
+      case 64:  return launch_vec<16>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge);
+      case 128: return launch_vec<32>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge);
+      case 256: return launch_vec<64>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge);
       default: break;
     }
   }
   int P = 1;
   while (P < F && P < 64) P <<= 1;
   int grid = gs_grid(N, AGG_BLOCK / 64, 256 * 64);
-  if (edge_weight)
-    hipLaunchKernelGGL((seg_gather_scalar_k<true>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr, col,
+  if (edge_weight && per_edge)
+    hipLaunchKernelGGL((seg_gather_scalar_k<2>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr, col,
+                       row_scale, edge_weight, x, add_to, N, F, out, P);
+  else if (edge_weight)
+    hipLaunchKernelGGL((seg_gather_scalar_k<1>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr, col,
                        row_scale, edge_weight, x, add_to, N, F, out, P);
   else
-    hipLaunchKernelGGL((seg_gather_scalar_k<false>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
-                       col, row_scale, edge_weight, x, add_to, N, F, out, P);
+    hipLaunchKernelGGL((seg_gather_scalar_k<0>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr, col,
+                       row_scale, edge_weight, x, add_to, N, F, out, P);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
+}
+
+extern "C" int gsage_segment_gather(const int32_t *rowptr, const int32_t *col,
+                                    const float *row_scale, const float *edge_weight,
+                                    const float *x, const float *add_to, int64_t N, int64_t F,
+                                    float *out, const int32_t *long_rows, const int32_t *n_long,
+                                    gsage_stream_t stream) {
+  return segment_gather_impl(rowptr, col, row_scale, edge_weight, false, x, add_to, N, F, out,
+                             long_rows, n_long, stream);
+}
+
+extern "C" int gsage_segment_gather_ew(const int32_t *rowptr, const int32_t *col,
+                                       const float *edge_w, const float *x, int64_t N, int64_t F,
+                                       float *out, const int32_t *long_rows,
+                                       const int32_t *n_long, gsage_stream_t stream) {
+  if (!edge_w) return GSAGE_ERR_INVALID_ARG;
+  return segment_gather_impl(rowptr, col, nullptr, edge_w, true, x, nullptr, N, F, out, long_rows,
+                             n_long, stream);
 }

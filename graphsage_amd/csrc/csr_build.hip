@@ -7,16 +7,19 @@
 // the order inside a bucket is the input order (tile, wave, round, lane) = stable.
 // Everything is integer work: results are bit-exact and run-to-run identical.
 #include "gsage_common.h"
+#include "gsage_sort.h"
 
 namespace {
 
 constexpr int SCAN_T = 256;
 constexpr int SCAN_IPT = 8;
 constexpr int SCAN_CH = SCAN_T * SCAN_IPT;  // 2048 ints per block
+static_assert(SCAN_CH == GS_SCAN_CH, "gsage_sort.h out of sync");
 
 constexpr int RS_T = 256;                   // radix sort block
 constexpr int RS_ROUNDS = 16;               // items per lane
 constexpr int RS_TILE = RS_T * RS_ROUNDS;   // 4096 items per block
+static_assert(RS_TILE == GS_RS_TILE, "gsage_sort.h out of sync");
 constexpr int RS_WAVE_ITEMS = 64 * RS_ROUNDS;
 
 constexpr int LONG_ROW_T = 2048;            // rows longer than this take the hub pass
@@ -153,8 +156,10 @@ __global__ void scan_apply_k(const int *__restrict__ in, int64_t n,
   }
 }
 
+}  // namespace
+
 // exclusive scan of in[0..n) into out[0..n) (in may equal out); bsum: ceil(n/SCAN_CH) ints
-int exclusive_scan(const int *in, int64_t n, int *out, int *bsum, hipStream_t st) {
+int gs_exclusive_scan(const int *in, int64_t n, int *out, int *bsum, hipStream_t st) {
   if (n <= 0) return GSAGE_OK;
   int64_t nb = (n + SCAN_CH - 1) / SCAN_CH;
   hipLaunchKernelGGL(scan_reduce_k, dim3((unsigned)nb), dim3(SCAN_T), 0, st, in, n, bsum);
@@ -163,6 +168,17 @@ int exclusive_scan(const int *in, int64_t n, int *out, int *bsum, hipStream_t st
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }
+
+int gs_list_long_rows(const int *rowptr, int64_t N, int *list, int64_t cap, int *count,
+                      hipStream_t st) {
+  if (N <= 0) return GSAGE_OK;
+  hipLaunchKernelGGL(long_rows_k, dim3(gs_grid(N, 256)), dim3(256), 0, st, rowptr, N, list, cap,
+                     count);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}
+
+namespace {
 
 // ------------------------------------------------------------------------ radix pass
 __global__ void radix_hist_k(const int *__restrict__ keys, int64_t n, int shift, int mask,
@@ -246,13 +262,11 @@ radix_scatter_k(const int *__restrict__ kin, const int *__restrict__ vin, int64_
   }
 }
 
-struct SortWs {
-  int *kA, *vA, *kB, *vB, *counts, *bsum;
-};
+}  // namespace
 
 // stable sort of (key,val) by key in [0, 2^bits); the sorted values land in vout_final.
-int radix_sort_vals(const int *keys, const int *vals, int64_t n, int bits, int *vout_final,
-                    const SortWs &ws, hipStream_t st) {
+int gs_radix_sort_vals(const int *keys, const int *vals, int64_t n, int bits, int *vout_final,
+                       const GsSortWs &ws, hipStream_t st) {
   if (n <= 0) return GSAGE_OK;
   if (bits < 1) bits = 1;
   int passes = (bits + 7) / 8;
@@ -268,7 +282,7 @@ int radix_sort_vals(const int *keys, const int *vals, int64_t n, int bits, int *
     hipLaunchKernelGGL(radix_hist_k, dim3((unsigned)ntiles), dim3(RS_T), 0, st, kin, n, shift,
                        mask, ws.counts, ntiles);
     int64_t ncounts = (int64_t)(mask + 1) * ntiles;
-    int rc = exclusive_scan(ws.counts, ncounts, ws.counts, ws.bsum, st);
+    int rc = gs_exclusive_scan(ws.counts, ncounts, ws.counts, ws.bsum, st);
     if (rc) return rc;
     hipLaunchKernelGGL(radix_scatter_k, dim3((unsigned)ntiles), dim3(RS_T), 0, st, kin, vin, n,
                        shift, mask, width, ws.counts, ntiles, kout, vout);
@@ -278,6 +292,8 @@ int radix_sort_vals(const int *keys, const int *vals, int64_t n, int bits, int *
   }
   return GSAGE_OK;
 }
+
+namespace {
 
 struct CsrWsLayout {
   size_t total;
@@ -337,7 +353,7 @@ extern "C" int gsage_csr_build(const int64_t *edge_index, int64_t E, int64_t N, 
   hipStream_t st = gs_stream(stream);
   char *b = (char *)ws;
   int *src32 = (int *)(b + L.o_src), *dst32 = (int *)(b + L.o_dst);
-  SortWs sw{(int *)(b + L.o_kA), (int *)(b + L.o_vA), (int *)(b + L.o_kB),
+  GsSortWs sw{(int *)(b + L.o_kA), (int *)(b + L.o_vA), (int *)(b + L.o_kB),
             (int *)(b + L.o_vB), (int *)(b + L.o_counts), (int *)(b + L.o_bsum)};
   int *deg = (int *)(b + L.o_deg);
 
@@ -364,15 +380,14 @@ extern "C" int gsage_csr_build(const int64_t *edge_index, int64_t E, int64_t N, 
       hipLaunchKernelGGL(inv_deg_k, dim3(gs_grid(N, 256)), dim3(256), 0, st, deg, N, inv_deg);
     GSAGE_CHECK_LAUNCH();
     // rowptr[0..N] = exclusive scan of deg[0..N] (deg[N] = dropped edges)
-    int rc = exclusive_scan(deg, N + 1, rp, sw.bsum, st);
+    int rc = gs_exclusive_scan(deg, N + 1, rp, sw.bsum, st);
     if (rc) return rc;
-    rc = radix_sort_vals(key, val, E, bits, cl, sw, st);
+    rc = gs_radix_sort_vals(key, val, E, bits, cl, sw, st);
     if (rc) return rc;
     int32_t *lr = orient == 0 ? long_rows : long_rows_t;
     if (lr && n_long && N > 0 && long_cap > 0) {
-      hipLaunchKernelGGL(long_rows_k, dim3(gs_grid(N, 256)), dim3(256), 0, st, rp, N, lr, long_cap,
-                         n_long + orient);
-      GSAGE_CHECK_LAUNCH();
+      rc = gs_list_long_rows(rp, N, lr, long_cap, n_long + orient, st);
+      if (rc) return rc;
     }
   }
   return GSAGE_OK;

@@ -1,0 +1,22 @@
+// Integer building blocks shared by the CSR build (K1) and the deterministic loss backward:
+// exclusive scan and stable LSD radix sort of (key, value) pairs (defined in csr_build.hip).
+#pragma once
+#include "gsage_common.h"
+
+constexpr int GS_SCAN_CH = 2048;   // ints per scan workgroup
+constexpr int GS_RS_TILE = 4096;   // items per radix-sort workgroup
+
+struct GsSortWs {
+  int *kA, *vA, *kB, *vB;   // ping-pong buffers, n ints each
+  int *counts;              // 256 * ceil(n / GS_RS_TILE) ints
+  int *bsum;                // ceil(max(scan length) / GS_SCAN_CH) + 1 ints
+};
+
+// exclusive scan of in[0..n) into out[0..n); in may equal out
+int gs_exclusive_scan(const int *in, int64_t n, int *out, int *bsum, hipStream_t st);
+// stable sort of (keys, vals) by key in [0, 2^bits); the sorted values land in vout_final
+int gs_radix_sort_vals(const int *keys, const int *vals, int64_t n, int bits, int *vout_final,
+                       const GsSortWs &ws, hipStream_t st);
+// ids of rows longer than gsage_long_row_threshold() -> list[0..*count) (count pre-zeroed)
+int gs_list_long_rows(const int *rowptr, int64_t N, int *list, int64_t cap, int *count,
+                      hipStream_t st);

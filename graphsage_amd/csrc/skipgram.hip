@@ -12,6 +12,7 @@
 // wave-instruction adds 256 contiguous bytes (the shape that runs at the full
 // float-atomic rate on MI355X).
 #include "gsage_common.h"
+#include "gsage_sort.h"
 
 namespace {
 
@@ -215,6 +216,101 @@ skipgram_bwd_k(const float *__restrict__ emb, int64_t N, int64_t D, const int64_
   }
 }
 
+
+// ------------------------------------------------------- deterministic backward (no atomics)
+// Every pair contributes 2(1+K) terms  grad_emb[dst] += w * emb[src].  The terms are listed,
+// stably sorted by dst with the K1 radix sort (term id as payload, so equal dst keep term
+// order), turned into a per-batch CSR and summed by the segment-gather kernel with per-term
+// weights: grad_emb is written row by row in a fixed order => bitwise reproducible, and no
+// zero-fill pass is needed.
+//   term s of pair b, R = 1+K:  s <  R: dst = t_b,            src = role(s)   (c_b or n_b,s-1)
+//                               s >= R: dst = role(s-R),      src = t_b        weight coef[b][s mod R]
+__device__ __forceinline__ void sg_term(const int64_t *__restrict__ tg, const int64_t *__restrict__ ctx,
+                                        const int64_t *__restrict__ neg, int64_t K, int64_t b, int s,
+                                        int64_t &dst, int64_t &src, int &r) {
+  const int R = 1 + (int)K;
+  r = s < R ? s : s - R;
+  int64_t t = tg[b];
+  int64_t o = r == 0 ? ctx[b] : neg[b * K + r - 1];
+  dst = s < R ? t : o;
+  src = s < R ? o : t;
+}
+
+__global__ void __launch_bounds__(256)
+sg_terms_k(const int64_t *__restrict__ tg, const int64_t *__restrict__ ctx,
+           const int64_t *__restrict__ neg, int64_t B, int64_t K, int64_t N, int *__restrict__ key,
+           int *__restrict__ val, int *__restrict__ deg) {
+  const int64_t M = B * 2 * (1 + K);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < M; e += stride) {
+    int64_t b = e / (2 * (1 + K));
+    int s = (int)(e % (2 * (1 + K)));
+    int64_t dst, src;
+    int r;
+    sg_term(tg, ctx, neg, K, b, s, dst, src, r);
+    bool bad = (uint64_t)dst >= (uint64_t)N || (uint64_t)src >= (uint64_t)N;
+    int k = bad ? (int)N : (int)dst;          // sentinel row N: sorted last, never read
+    key[e] = k;
+    val[e] = (int)e;
+    atomicAdd(&deg[k], 1);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+sg_materialise_k(const int *__restrict__ perm, const int64_t *__restrict__ tg,
+                 const int64_t *__restrict__ ctx, const int64_t *__restrict__ neg, int64_t B,
+                 int64_t K, int64_t N, const float *__restrict__ coef,
+                 const float *__restrict__ grad_loss, int *__restrict__ col, float *__restrict__ w) {
+  const int64_t M = B * 2 * (1 + K);
+  const float g = *grad_loss;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < M; p += stride) {
+    int64_t e = perm[p];
+    int64_t b = e / (2 * (1 + K));
+    int s = (int)(e % (2 * (1 + K)));
+    int64_t dst, src;
+    int r;
+    sg_term(tg, ctx, neg, K, b, s, dst, src, r);
+    bool bad = (uint64_t)dst >= (uint64_t)N || (uint64_t)src >= (uint64_t)N;
+    col[p] = bad ? 0 : (int)src;
+    w[p] = bad ? 0.f : coef[b * (1 + K) + r] * g;
+  }
+}
+
+struct DetLayout {
+  size_t total, o_key, o_val, o_kA, o_vA, o_kB, o_vB, o_counts, o_bsum, o_deg, o_rowptr, o_col,
+      o_w, o_long, o_nlong;
+  int64_t M, long_cap;
+};
+
+DetLayout det_layout(int64_t N, int64_t B, int64_t K) {
+  DetLayout L;
+  L.M = B * 2 * (1 + K);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += gs_align_up(bytes ? bytes : 4, 256);
+    return o;
+  };
+  size_t m4 = (size_t)L.M * 4;
+  int64_t ntiles = (L.M + GS_RS_TILE - 1) / GS_RS_TILE;
+  int64_t ncounts = 256 * (ntiles > 0 ? ntiles : 1);
+  int64_t scan_n = ncounts > (N + 2) ? ncounts : (N + 2);
+  L.long_cap = L.M / gsage_long_row_threshold() + 1;
+  L.o_key = take(m4); L.o_val = take(m4);
+  L.o_kA = take(m4); L.o_vA = take(m4); L.o_kB = take(m4); L.o_vB = take(m4);
+  L.o_counts = take((size_t)ncounts * 4);
+  L.o_bsum = take((size_t)((scan_n + GS_SCAN_CH - 1) / GS_SCAN_CH + 1) * 4);
+  L.o_deg = take((size_t)(N + 2) * 4);
+  L.o_rowptr = take((size_t)(N + 2) * 4);
+  L.o_col = take(m4);
+  L.o_w = take(m4);
+  L.o_long = take((size_t)L.long_cap * 4);
+  L.o_nlong = take(16);
+  L.total = off;
+  return L;
+}
+
 int sg_blocks(int64_t B, int pairs_per_block) {
   int64_t nb = (B + pairs_per_block - 1) / pairs_per_block;
   if (nb < 1) nb = 1;
@@ -283,4 +379,56 @@ extern "C" int gsage_skipgram_bwd(const float *emb, int64_t N, int64_t D, const 
                      negatives, B, K, coef, grad_loss, grad_emb);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
+}
+
+extern "C" size_t gsage_skipgram_bwd_det_workspace_bytes(int64_t N, int64_t B, int64_t K) {
+  if (N <= 0 || B <= 0 || K < 0) return 0;
+  return det_layout(N, B, K).total;
+}
+
+extern "C" int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D,
+                                      const int64_t *targets, const int64_t *contexts,
+                                      const int64_t *negatives, int64_t B, int64_t K,
+                                      const float *coef, const float *grad_loss, float *grad_emb,
+                                      void *ws, size_t ws_bytes, gsage_stream_t stream) {
+  if (N <= 0 || D <= 0 || B <= 0 || K < 0 || !emb || !targets || !contexts || !coef ||
+      !grad_loss || !grad_emb || !ws)
+    return GSAGE_ERR_INVALID_ARG;
+  if (K > 0 && !negatives) return GSAGE_ERR_INVALID_ARG;
+  DetLayout L = det_layout(N, B, K);
+  if (L.M >= (1ll << 31) - 1 || N >= (1ll << 31) - 2) return GSAGE_ERR_UNSUPPORTED;
+  if (ws_bytes < L.total) return GSAGE_ERR_WORKSPACE;
+  hipStream_t st = gs_stream(stream);
+  char *b = (char *)ws;
+  int *key = (int *)(b + L.o_key), *val = (int *)(b + L.o_val);
+  GsSortWs sw{(int *)(b + L.o_kA), (int *)(b + L.o_vA), (int *)(b + L.o_kB), (int *)(b + L.o_vB),
+              (int *)(b + L.o_counts), (int *)(b + L.o_bsum)};
+  int *deg = (int *)(b + L.o_deg), *rowptr = (int *)(b + L.o_rowptr);
+  int *col = (int *)(b + L.o_col);
+  float *w = (float *)(b + L.o_w);
+  int *longs = (int *)(b + L.o_long), *nlong = (int *)(b + L.o_nlong);
+
+  if (hipMemsetAsync(deg, 0, (size_t)(N + 2) * 4, st) != hipSuccess ||
+      hipMemsetAsync(nlong, 0, 16, st) != hipSuccess)
+    return GSAGE_ERR_LAUNCH;
+  hipLaunchKernelGGL(sg_terms_k, dim3(gs_grid(L.M, 256)), dim3(256), 0, st, targets, contexts,
+                     negatives, B, K, N, key, val, deg);
+  GSAGE_CHECK_LAUNCH();
+  int rc = gs_exclusive_scan(deg, N + 1, rowptr, sw.bsum, st);
+  if (rc) return rc;
+  int bits = 0;
+  while ((1ll << bits) <= N) ++bits;
+  int *perm = key;   // the keys are dead after the sort's first pass has read them: reuse
+  // (the first pass reads `key` and writes kA/vA; the last pass writes `perm`; with a single
+  //  pass it would read and write the same array, so that case sorts into vB instead)
+  int passes = (bits + 7) / 8;
+  if (passes == 1) perm = sw.vB;
+  rc = gs_radix_sort_vals(key, val, L.M, bits, perm, sw, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sg_materialise_k, dim3(gs_grid(L.M, 256)), dim3(256), 0, st, perm, targets,
+                     contexts, negatives, B, K, N, coef, grad_loss, col, w);
+  GSAGE_CHECK_LAUNCH();
+  rc = gs_list_long_rows(rowptr, N, longs, L.long_cap, nlong, st);
+  if (rc) return rc;
+  return gsage_segment_gather_ew(rowptr, col, w, emb, N, D, grad_emb, longs, nlong, stream);
 }

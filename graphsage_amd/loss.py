@@ -21,9 +21,12 @@ DETAIL_KEYS = ("total_loss", "pos_loss", "neg_loss", "pos_score_mean", "neg_scor
 class SkipGramLoss(nn.Module):
     """L = -mean_b log s(s*<e_t,e_c>) - mean_{b,k} log s(-s*<e_n,e_t>), s = scale_factor."""
 
-    def __init__(self, scale_factor: float = 5.0):
+    def __init__(self, scale_factor: float = 5.0, deterministic: Optional[bool] = None):
+        """``deterministic``: True = sort-based backward (bitwise reproducible gradients),
+        False = float-atomic scatter (fastest), None = follow GSAGE_LOSS_BWD (default atomic)."""
         super().__init__()
         self.scale_factor = scale_factor
+        self.deterministic = deterministic
 
     def _run(self, embeddings, targets, contexts, negatives, global_batch: Optional[int]):
         B = targets.numel()
@@ -31,7 +34,7 @@ class SkipGramLoss(nn.Module):
         gb = B if global_batch is None else int(global_batch)
         return SkipGramFunction.apply(embeddings, targets, contexts, negatives,
                                       float(self.scale_factor), float(gb),
-                                      float(gb * max(K, 1)))
+                                      float(gb * max(K, 1)), self.deterministic)
 
     def forward(self, embeddings: torch.Tensor, targets: torch.Tensor, contexts: torch.Tensor,
                 negatives: torch.Tensor, global_batch: Optional[int] = None) -> torch.Tensor:

@@ -96,6 +96,14 @@ int gsage_segment_gather(const int32_t *rowptr, const int32_t *col,
                          float *out, const int32_t *long_rows, const int32_t *n_long,
                          gsage_stream_t stream);
 
+/* Weighted variant: out[i,:] = sum_{p in row i} edge_w[p] * x[col[p],:] with one weight per
+ * CSR entry (same order as col).  Used by the deterministic loss backward; also the SpMM a
+ * weighted graph would need. */
+int gsage_segment_gather_ew(const int32_t *rowptr, const int32_t *col, const float *edge_w,
+                            const float *x, int64_t N, int64_t F, float *out,
+                            const int32_t *long_rows, const int32_t *n_long,
+                            gsage_stream_t stream);
+
 /* ------------------------------------------------------------ K3: fused projection
  * Replaces `F.linear(agg, W_l, b_l) + F.linear(x, W_r)` (PyG SAGEConv.forward) fused
  * with F.relu / nn.Dropout (graphsage.py:134-135) or F.normalize (graphsage.py:141-142).
@@ -167,6 +175,18 @@ int gsage_skipgram_bwd(const float *emb, int64_t N, int64_t D, const int64_t *ta
                        const int64_t *contexts, const int64_t *negatives, int64_t B,
                        int64_t K, const float *coef, const float *grad_loss,
                        float *grad_emb, gsage_stream_t stream);
+
+/* K5, deterministic form: the same gradient as gsage_skipgram_bwd without atomics.  The
+ * 2(1+K) terms of every pair are stably sorted by destination row (K1's radix sort) into a
+ * per-batch CSR and summed by the segment gather in a fixed order: bitwise reproducible.
+ * grad_emb [N,D] is OVERWRITTEN (rows no pair touches become zero): no zero-fill needed.
+ *   ws: gsage_skipgram_bwd_det_workspace_bytes(N, B, K) bytes.
+ */
+size_t gsage_skipgram_bwd_det_workspace_bytes(int64_t N, int64_t B, int64_t K);
+int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D, const int64_t *targets,
+                           const int64_t *contexts, const int64_t *negatives, int64_t B,
+                           int64_t K, const float *coef, const float *grad_loss,
+                           float *grad_emb, void *ws, size_t ws_bytes, gsage_stream_t stream);
 
 /* ------------------------------------------- feeder: alias table (HOST pointers, host code)
  * Replaces the interpreter loop of DegreeBiasedNegativeSampler._setup_alias_table

@@ -119,3 +119,45 @@ def test_rejects_wrong_inputs():
         SkipGramLoss()(emb, t.int(), t, neg)
     with pytest.raises(ValueError):
         SkipGramLoss()(emb.cpu(), t.cpu(), t.cpu(), neg.cpu())     # no CPU path
+
+
+@pytest.mark.parametrize("n,d,b,k,hot", [(5000, 64, 4096, 5, False), (300, 64, 30000, 5, True),
+                                         (2000, 128, 1000, 3, False), (100, 30, 500, 7, False),
+                                         (50, 64, 7, 0, False)])
+def test_deterministic_and_atomic_backward_agree_with_oracle(n, d, b, k, hot):
+    """K5 in both forms.  `hot`: every pair shares one target, so its row of the per-batch CSR
+    (b*(1+k) terms) goes through the hub-row path."""
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(n + b)
+    emb = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).requires_grad_()
+    t = torch.full((b,), 5, dtype=torch.int64) if hot else torch.randint(0, n, (b,), generator=g)
+    c = torch.randint(0, n, (b,), generator=g)
+    neg = torch.randint(0, n, (b, k), generator=g)
+    if k > 0:
+        O.skipgram_loss(emb, t, c, neg, 5.0).backward()
+    else:   # no negatives: only the positive term exists
+        (-torch.nn.functional.logsigmoid((emb[t] * emb[c]).sum(1) * 5.0).mean()).backward()
+    e, tt, cc, nn_ = emb.detach().cuda(), t.cuda(), c.cuda(), neg.cuda()
+    coef, _ = ops.skipgram_fwd(e, tt, cc, nn_, 5.0)
+    one = torch.ones((), device="cuda")
+    det1 = ops.skipgram_bwd(e, tt, cc, nn_, coef, one, deterministic=True)
+    det2 = ops.skipgram_bwd(e, tt, cc, nn_, coef, one, deterministic=True)
+    atom = ops.skipgram_bwd(e, tt, cc, nn_, coef, one, deterministic=False)
+    assert torch.equal(det1, det2)                              # bitwise reproducible
+    assert_close(det1, emb.grad, rtol=1e-5, floor=2e-6, what="deterministic")
+    assert_close(atom, emb.grad, rtol=1e-5, floor=2e-6, what="atomic")
+
+
+def test_deterministic_backward_ignores_out_of_range_pairs():
+    from graphsage_amd import ops
+    emb = torch.randn(10, 64).cuda()
+    t = torch.tensor([1, 2, 3]).cuda()
+    c = torch.tensor([3, 10, 4]).cuda()                         # pair 1 has a bad context id
+    neg = torch.tensor([[1, 2], [3, 4], [5, -1]]).cuda()        # pair 2 has a bad negative
+    coef, stats = ops.skipgram_fwd(emb, t, c, neg, 5.0)
+    assert stats[7].item() != 0
+    one = torch.ones((), device="cuda")
+    d = ops.skipgram_bwd(emb, t, c, neg, coef, one, deterministic=True)
+    a = ops.skipgram_bwd(emb, t, c, neg, coef, one, deterministic=False)
+    assert torch.isfinite(d).all()
+    assert_close(d, a, rtol=1e-5, floor=2e-6)
