@@ -660,7 +660,7 @@ proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
 //   [grad_agg | grad_x] = dpre . [W_l | W_r]   (MFMA, weights in registers; grad_agg * scale)
 //   dW += dpre^T . [agg | x], db += colsum     (MFMA over the row index, kept in registers
 //                                               across the workgroup's tiles -> one slab)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
               const float *__restrict__ rnorm, const float *__restrict__ agg,
               const float *__restrict__ x, const float *__restrict__ bp /* [128][64] */,
@@ -780,7 +780,7 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
 }
 
 constexpr int S64_GRID = 256 * 3;   // persistent workgroups (3 per CU fit LDS)
-constexpr int S64_BWD_GRID = 256 * 2;
+constexpr int S64_BWD_GRID = 256 * 3;
 
 // =============================================================================== VALU
 // small-K forward (2*Fi <= 16, Fo <= 64): wave per row, lane = output column, weights in
