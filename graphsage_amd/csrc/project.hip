@@ -825,6 +825,88 @@ project_fwd_smallk_k(const float *__restrict__ agg, const float *__restrict__ x,
   }
 }
 
+
+// first-layer forward on the matrix cores: Fi = 8 (the 7 memory features padded), so
+// K = [agg | x] = 16.  Computed transposed, D^T[n][row] = sum_k W^T[n][k] * cat[row][k], with
+// v_mfma_f32_16x16x4_f32: lane (row = l&15, q = l>>4) loads ONE float4 of its row
+// (q = 0,1: agg columns 0-3 / 4-7; q = 2,3: x columns) and ends up holding 4 consecutive output
+// columns of that row per 16-column tile, so outputs leave as 16-byte stores.  The weights sit
+// in 16 registers per lane for the whole launch.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
+                  const float *__restrict__ wt /* [16][Fo] */, int64_t N, int Fo, EpiArgs e,
+                  float *__restrict__ out) {
+  const int lane = gs_lane();
+  const int rl = lane & 15, q = lane >> 4;
+  const int cb = blockIdx.y * 64;              // this workgroup's 64 output columns
+  // A operand of step s, tile nt: W^T[n = cb+16nt+rl][k' = 4q+s]
+  float wreg[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) wreg[nt][s2] = wt[(4 * q + s2) * Fo + cb + 16 * nt + rl];
+  float4 bias[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) bias[nt] = *(const float4 *)(e.bias + cb + 16 * nt + 4 * q);
+  const float *src = q < 2 ? agg + 4 * q : x + 4 * (q - 2);
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = wave0 * 16; r0 < N; r0 += nwaves * 16) {
+    const int64_t row = r0 + rl;
+    const bool live = row < N;
+    float4 c = live ? *(const float4 *)(src + row * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][0], c.x, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][1], c.y, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][2], c.z, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][3], c.w, acc[nt], 0, 0, 0);
+    }
+    // acc[nt][reg] = out[row][cb + 16nt + 4q + reg]
+    float4 v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      v[nt] = make_float4(acc[nt][0] + bias[nt].x, acc[nt][1] + bias[nt].y,
+                          acc[nt][2] + bias[nt].z, acc[nt][3] + bias[nt].w);
+      if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) {
+        v[nt].x = fmaxf(v[nt].x, 0.f); v[nt].y = fmaxf(v[nt].y, 0.f);
+        v[nt].z = fmaxf(v[nt].z, 0.f); v[nt].w = fmaxf(v[nt].w, 0.f);
+      }
+      if (e.mode == GSAGE_EPI_RELU_DROPOUT && live) {
+        uint64_t idx = (uint64_t)row * (uint64_t)Fo + (uint64_t)(cb + 16 * nt + 4 * q);
+        bool k0, k1, k2, k3;
+        if (e.keep_mask) {
+          uchar4 m = *(const uchar4 *)(e.keep_mask + idx);
+          k0 = m.x; k1 = m.y; k2 = m.z; k3 = m.w;
+        } else {
+          k0 = dropout_keep(e.seed, idx + 0, e.p); k1 = dropout_keep(e.seed, idx + 1, e.p);
+          k2 = dropout_keep(e.seed, idx + 2, e.p); k3 = dropout_keep(e.seed, idx + 3, e.p);
+        }
+        v[nt].x = k0 ? v[nt].x * e.inv_keep : 0.f; v[nt].y = k1 ? v[nt].y * e.inv_keep : 0.f;
+        v[nt].z = k2 ? v[nt].z * e.inv_keep : 0.f; v[nt].w = k3 ? v[nt].w * e.inv_keep : 0.f;
+      }
+      ss += v[nt].x * v[nt].x + v[nt].y * v[nt].y + v[nt].z * v[nt].z + v[nt].w * v[nt].w;
+    }
+    if (e.mode == GSAGE_EPI_L2NORM) {          // launched with one column block only
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { v[nt].x *= rn; v[nt].y *= rn; v[nt].z *= rn; v[nt].w *= rn; }
+      if (live && q == 0 && e.rnorm) e.rnorm[row] = rn;
+    }
+    if (live) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *(float4 *)(out + row * Fo + cb + 16 * nt + 4 * q) = v[nt];
+    }
+  }
+}
+
 // generic forward: wave per row, lanes stride the output columns; Wt from L1/L2.
 __global__ void __launch_bounds__(256)
 project_fwd_generic_k(const float *__restrict__ agg, const float *__restrict__ x,
@@ -961,7 +1043,6 @@ dw_smallk_k(const float *__restrict__ dpre, const float *__restrict__ out_saved,
 // dimension of v_mfma_f32_16x16x4_f32, float4 component c of a lane is tile c of dpre^T
 // (m = 4*sub + c) and the lane's single [agg | x] value is the B operand: 4 MFMAs per 4 rows,
 // no cross-lane traffic.  ReLU'(+dropout') is applied on the fly from the saved output.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DW16_SLAB = 64 * 16 + 64;   // [m][k'] then bias[m]; k' < 8: agg col, else x col
 constexpr int DW16_BLOCKS = 256 * 4;
 
@@ -1177,7 +1258,12 @@ extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *
   }
   hipLaunchKernelGGL(pack_t_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
   int grid = gs_grid(N, 4, 256 * 16);
-  if (2 * Fi <= 16 && (Fo <= 64 || (Fo % 64 == 0 && epilogue != GSAGE_EPI_L2NORM)))
+  if (force_generic == 0 && Fi == 8 && Fo % 64 == 0 && (Fo == 64 || epilogue != GSAGE_EPI_L2NORM) &&
+      ((((uintptr_t)agg | (uintptr_t)x | (uintptr_t)out | (uintptr_t)b_l | (uintptr_t)keep_mask) & 15) == 0)) {
+    int g16 = gs_grid(N, 64, 256 * 8);
+    hipLaunchKernelGGL(project_fwd_k16_k, dim3(g16, fo / 64), dim3(256), 0, st, agg, x, wp, N, fo, e,
+                       out);
+  } else if (2 * Fi <= 16 && (Fo <= 64 || (Fo % 64 == 0 && epilogue != GSAGE_EPI_L2NORM)))
     hipLaunchKernelGGL((project_fwd_smallk_k<16>), dim3(grid, (fo + 63) / 64), dim3(256), 0, st, agg,
                        x, wp, N, fi, fo, e, out);
   else
