@@ -50,7 +50,7 @@ def measured_traffic(workload, F):
         return None, None
     try:
         z = json.load(open(best))
-        k = f"seg_gather_vec_k<{F // 4}, false>"
+        k = f"seg_gather_vec_k<{F // 4}, 0>"
         fetch_kb, write_kb = z["FETCH_SIZE"][k]["mean_KB"], z["WRITE_SIZE"][k]["mean_KB"]
         return (2.0 * fetch_kb + write_kb) * 1024.0, os.path.relpath(best, ROOT)
     except (KeyError, ValueError, OSError):
@@ -173,7 +173,7 @@ def main():
     alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if launches else float("nan")
     traffic, traffic_src = measured_traffic(args.workload, F)
-    roofline = {"bound": "hbm", "kernel": f"seg_gather_vec_k<{F // 4},false> (hub rows included), F={F}",
+    roofline = {"bound": "hbm", "kernel": f"seg_gather_vec_k<{F // 4},0> (hub rows included), F={F}",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "launches_timed": launches, "mean_ms": mean_ms, "algorithmic_bytes": alg_bytes}
