@@ -7,10 +7,12 @@ from .graph import GraphCSR, GraphCache, build_csr, default_cache
 from .train_step import TrainStep, FlatParams, shard_bounds
 from .sampler import DegreeBiasedNegativeSampler, UniformNegativeSampler
 from .encoder import StructuralEncoder, model_from_checkpoint
+from .walks import RandomWalkGenerator, CooccurrencePairSampler, estimate_pair_count
 from .trainer import GraphSAGETrainer, BatchGenerator, Batch, split_pairs_train_val
 
 __all__ = ["GraphSAGE", "SAGEConv", "create_model", "SkipGramLoss", "create_loss", "GraphCSR",
            "GraphCache", "build_csr", "default_cache", "TrainStep", "FlatParams", "shard_bounds", "DegreeBiasedNegativeSampler",
            "UniformNegativeSampler", "GraphSAGETrainer", "BatchGenerator", "Batch",
-           "split_pairs_train_val", "StructuralEncoder", "model_from_checkpoint"]
+           "split_pairs_train_val", "StructuralEncoder", "model_from_checkpoint",
+           "RandomWalkGenerator", "CooccurrencePairSampler", "estimate_pair_count"]
 __version__ = "0.1.0"

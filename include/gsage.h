@@ -188,6 +188,31 @@ int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D, const int64_t
                            int64_t K, const float *coef, const float *grad_loss,
                            float *grad_emb, void *ws, size_t ws_bytes, gsage_stream_t stream);
 
+/* ----------------------------------------------------- feeder: random walks and pair windows
+ * gsage_random_walks replaces RandomWalkGenerator.generate_all_walks (src/walks/generator.py:
+ * 119-195): walk w starts at node w / walks_per_node, takes up to walk_length nodes, each step a
+ * uniform choice among the out-neighbours (rowptr_t/col_t keep the reference's adjacency order),
+ * stops at a dead end.  walks: int32 [N*walks_per_node, walk_length], padded with -1;
+ * lengths: int32 [N*walks_per_node] (1 = isolated start; the reference drops those walks, they
+ * yield no pairs).  The random stream is a counter hash of (seed, walk, step), not Python's.
+ *
+ * gsage_walk_pair_counts / gsage_walk_pairs_gather replace CooccurrencePairSampler.extract_pairs
+ * (src/walks/pair_sampler.py:56-86) without materialising every pair: counts[w] = pairs of walk
+ * w; with offsets = exclusive prefix sum of counts (W+1 entries, int64), pair number `id` in the
+ * reference's enumeration order (walk, position i, window slot j) is decoded to
+ * (walks[w][i], walks[w][j]).  pair_ids == NULL means ids first_id .. first_id+B-1 (bulk
+ * extraction in reference order); otherwise any ids (uniform pair sampling for a batch).
+ */
+int gsage_random_walks(const int32_t *rowptr_t, const int32_t *col_t, int64_t N,
+                       int64_t walk_length, int64_t walks_per_node, uint64_t seed,
+                       int32_t *walks, int32_t *lengths, gsage_stream_t stream);
+int gsage_walk_pair_counts(const int32_t *lengths, int64_t W, int64_t window, int64_t *counts,
+                           gsage_stream_t stream);
+int gsage_walk_pairs_gather(const int32_t *walks, const int32_t *lengths, int64_t walk_length,
+                            const int64_t *offsets, int64_t W, const int64_t *pair_ids,
+                            int64_t first_id, int64_t B, int64_t window, int64_t *targets,
+                            int64_t *contexts, gsage_stream_t stream);
+
 /* ------------------------------------------- feeder: alias table (HOST pointers, host code)
  * Replaces the interpreter loop of DegreeBiasedNegativeSampler._setup_alias_table
  * (src/walks/negative_sampler.py:95-145).  scaled_probs[i] = probs[i] * n (float32).

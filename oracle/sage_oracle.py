@@ -237,3 +237,16 @@ def alias_table(edge_index: torch.Tensor, num_nodes: int, exponent: float = 0.75
     for s in smaller:
         prob_table[s] = 1.0
     return probs, torch.from_numpy(prob_table), torch.from_numpy(alias)
+
+
+# ------------------------------------------------ feeder: pair windows (next row, 8f-4)
+def extract_pairs(walks, context_window: int):
+    """Restatement of ``CooccurrencePairSampler.extract_pairs`` (src/walks/pair_sampler.py:56-86)."""
+    pairs = []
+    for walk in walks:
+        n = len(walk)
+        for i, target in enumerate(walk):
+            for j in range(max(0, i - context_window), min(n, i + context_window + 1)):
+                if i != j:
+                    pairs.append((target, walk[j]))
+    return pairs

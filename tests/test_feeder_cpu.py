@@ -101,3 +101,15 @@ def test_pair_window_golden_shape(golden_dir):
     pairs = {tuple(p) for p in z["pairs_w2"].tolist()}
     assert len(z["pairs_w2"]) == 14
     assert (0, 1) in pairs and (0, 2) in pairs and (0, 3) not in pairs and (2, 0) in pairs
+
+
+def test_oracle_pair_window_matches_reference_golden(golden_dir):
+    """oracle.extract_pairs reproduces the pair LIST (order included) the reference's own
+    CooccurrencePairSampler produced for tests/test_walks.py:98-118."""
+    from oracle import sage_oracle as O
+    z = np.load(os.path.join(golden_dir, "alias_golden.npz"))
+    got = O.extract_pairs([[0, 1, 2, 3, 4]], 2)
+    assert [list(p) for p in got] == z["pairs_w2"].tolist()
+    # pair_sampler.py:287-305: every position sees at most 2*window others
+    assert len(O.extract_pairs([[3]], 5)) == 0
+    assert len(O.extract_pairs([list(range(30))], 10)) <= 30 * 20
