@@ -107,10 +107,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal switch for a one-GPU box: all ranks on cuda:0 over gloo (RCCL needs one GPU per rank)
+    rehearse = os.environ.get("GSAGE_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        import faulthandler
+        faulthandler.dump_traceback_later(80, exit=True)
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            _all_reduce = dist.all_reduce
+
+            def staged_all_reduce(t, op=dist.ReduceOp.SUM, group=None):   # gloo sees host memory only
+                h = t.cpu()
+                _all_reduce(h, op=op, group=group)
+                t.copy_(h)
+            dist.all_reduce = staged_all_reduce
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
     if args.gpus != world:
         log(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     dev = torch.device(f"cuda:{local_rank}")
@@ -140,21 +156,32 @@ def main():
     nbatch = 4
     batches = [cooccurrence_batch(ei, nodes, B, K, seed=1000 * (rank + 1) + i) for i in range(nbatch)]
     torch.cuda.synchronize()
+    if rehearse:
+        print(f"[bench r{rank}] batches ready", file=sys.stderr, flush=True)
+
+    token = torch.zeros(1, device=dev)
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if world > 1:                      # barrier = a one-element all-reduce on the device
+            dist.all_reduce(token)
             torch.cuda.synchronize()
+        if rehearse:
+            print(f"[bench r{rank}] barrier passed", file=sys.stderr, flush=True)
 
     for i in range(args.warmup):
         step.step(*batches[i % nbatch], global_batch=B * world)
+        if rehearse:
+            torch.cuda.synchronize()
+            print(f"[bench r{rank}] warmup step {i} done", file=sys.stderr, flush=True)
     timer = ops.KernelTimer()
     ops.set_kernel_timer(timer)
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
         stats = step.step(*batches[i % nbatch], global_batch=B * world)
+        if rehearse:
+            print(f"[bench r{rank}] timed step {i} queued", file=sys.stderr, flush=True)
     sync_all()
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
