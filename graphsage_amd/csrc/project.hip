@@ -581,7 +581,7 @@ __device__ __forceinline__ void s64_stage_cat(const float *__restrict__ a1,
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
              const float *__restrict__ bp /* [64][128] */, int64_t M, EpiArgs e,
              float *__restrict__ out) {
@@ -596,10 +596,28 @@ proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
   const int rsub = t >> 4, c4 = (t & 15) * 4;
   const float4 bias = *(const float4 *)(e.bias + c4);
   const int64_t ntiles = (M + 63) / 64;
+  // operands of tile i+1 are fetched into registers underneath tile i's MFMAs and epilogue
+  float4 r1[4], r2[4];
+#define S64_FETCH(ROW0)                                                     \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                           \
+    int64_t row = (ROW0) + p * 16 + rsub;                                   \
+    bool in = row < M;                                                      \
+    row = in ? row : 0;                                                     \
+    r1[p] = *(const float4 *)(agg + row * 64 + c4);                         \
+    r2[p] = *(const float4 *)(x + row * 64 + c4);                           \
+    if (!in) { r1[p] = make_float4(0.f, 0.f, 0.f, 0.f); r2[p] = r1[p]; }    \
+  }
+  if ((int64_t)blockIdx.x < ntiles) { S64_FETCH((int64_t)blockIdx.x * 64) }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * 64;
-    s64_stage_cat(agg, x, row0, M, As);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *(float4 *)(As + (p * 16 + rsub) * S64_AP + c4) = r1[p];
+      *(float4 *)(As + (p * 16 + rsub) * S64_AP + 64 + c4) = r2[p];
+    }
     __syncthreads();
+    if (tile + gridDim.x < ntiles) { S64_FETCH((tile + gridDim.x) * 64) }
+#undef S64_FETCH
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -660,11 +678,12 @@ proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
 //   [grad_agg | grad_x] = dpre . [W_l | W_r]   (MFMA, weights in registers; grad_agg * scale)
 //   dW += dpre^T . [agg | x], db += colsum     (MFMA over the row index, kept in registers
 //                                               across the workgroup's tiles -> one slab)
-__global__ void __launch_bounds__(256, 3)
+template <int MODE>   // 0 = no epilogue, 1 = ReLU(+dropout), 2 = L2 normalisation
+__global__ void __launch_bounds__(256, 2)
 bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
               const float *__restrict__ rnorm, const float *__restrict__ agg,
               const float *__restrict__ x, const float *__restrict__ bp /* [128][64] */,
-              const float *__restrict__ agg_scale, int64_t M, int mode, float inv_keep,
+              const float *__restrict__ agg_scale, int64_t M, float inv_keep,
               float *__restrict__ grad_agg, float *__restrict__ grad_x,
               float *__restrict__ slabs) {
   __shared__ __align__(16) float Ac[64 * S64_AP];
@@ -685,45 +704,54 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
   float bsum = 0.f;
   const int rsub = t >> 4, c4 = (t & 15) * 4;
   const int64_t ntiles = (M + 63) / 64;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t row0 = tile * 64;
-    // ---- dpre tile
-    {
-      float4 gv[4], yv[4];
-      float rn[4];
+  // the tile's operands travel through registers: the loads of tile i+1 are issued right after
+  // tile i's operands reach LDS and complete underneath tile i's MFMAs
+  float4 gv[4], yv[4], av[4], xv[4];
+  float rn[4], scv = 1.f;
+  auto fetch = [&](int64_t row0) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        int64_t row = row0 + p * 16 + rsub;
-        if (row < M) {
-          gv[p] = *(const float4 *)(g + row * 64 + c4);
-          yv[p] = mode != GSAGE_EPI_NONE ? *(const float4 *)(y + row * 64 + c4) : gv[p];
-          rn[p] = mode == GSAGE_EPI_L2NORM ? rnorm[row] : 1.f;
-        } else {
-          gv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-          yv[p] = gv[p];
-          rn[p] = 0.f;
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        float4 d = gv[p];
-        if (mode == GSAGE_EPI_L2NORM) {
-          float dot = gv[p].x * yv[p].x + gv[p].y * yv[p].y + gv[p].z * yv[p].z + gv[p].w * yv[p].w;
-          dot += __shfl_xor(dot, 8, 64); dot += __shfl_xor(dot, 4, 64);
-          dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 1, 64);
-          if (rn[p] >= 0.5f / L2_EPS) dot = 0.f;   // clamped norm: dy/dx = I / eps
-          d.x = (gv[p].x - yv[p].x * dot) * rn[p]; d.y = (gv[p].y - yv[p].y * dot) * rn[p];
-          d.z = (gv[p].z - yv[p].z * dot) * rn[p]; d.w = (gv[p].w - yv[p].w * dot) * rn[p];
-        } else if (mode != GSAGE_EPI_NONE) {
-          d.x = yv[p].x > 0.f ? d.x * inv_keep : 0.f; d.y = yv[p].y > 0.f ? d.y * inv_keep : 0.f;
-          d.z = yv[p].z > 0.f ? d.z * inv_keep : 0.f; d.w = yv[p].w > 0.f ? d.w * inv_keep : 0.f;
-        }
-        *(float4 *)(Dp + (p * 16 + rsub) * S64_DP + c4) = d;
+    for (int p = 0; p < 4; ++p) {
+      int64_t row = row0 + p * 16 + rsub;
+      if (row < M) {
+        gv[p] = *(const float4 *)(g + row * 64 + c4);
+        if (MODE != 0) yv[p] = *(const float4 *)(y + row * 64 + c4);
+        if (MODE == 2) rn[p] = rnorm[row];
+        av[p] = *(const float4 *)(agg + row * 64 + c4);
+        xv[p] = *(const float4 *)(x + row * 64 + c4);
+      } else {
+        gv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        yv[p] = gv[p]; av[p] = gv[p]; xv[p] = gv[p];
+        rn[p] = 0.f;
       }
     }
-    s64_stage_cat(agg, x, row0, M, Ac);
-    if (t < 64) sc[t] = (agg_scale && row0 + t < M) ? agg_scale[row0 + t] : 1.f;
+    if (t < 64) scv = (agg_scale && row0 + t < M) ? agg_scale[row0 + t] : 1.f;
+  };
+  if ((int64_t)blockIdx.x < ntiles) fetch((int64_t)blockIdx.x * 64);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * 64;
+    // ---- dpre tile and [agg | x] tile into LDS
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float4 d = gv[p];
+      if (MODE == 2) {
+        float dot = gv[p].x * yv[p].x + gv[p].y * yv[p].y + gv[p].z * yv[p].z + gv[p].w * yv[p].w;
+        dot += __shfl_xor(dot, 8, 64); dot += __shfl_xor(dot, 4, 64);
+        dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 1, 64);
+        if (rn[p] >= 0.5f / L2_EPS) dot = 0.f;   // clamped norm: dy/dx = I / eps
+        d.x = (gv[p].x - yv[p].x * dot) * rn[p]; d.y = (gv[p].y - yv[p].y * dot) * rn[p];
+        d.z = (gv[p].z - yv[p].z * dot) * rn[p]; d.w = (gv[p].w - yv[p].w * dot) * rn[p];
+      } else if (MODE == 1) {
+        d.x = yv[p].x > 0.f ? d.x * inv_keep : 0.f; d.y = yv[p].y > 0.f ? d.y * inv_keep : 0.f;
+        d.z = yv[p].z > 0.f ? d.z * inv_keep : 0.f; d.w = yv[p].w > 0.f ? d.w * inv_keep : 0.f;
+      }
+      int r = p * 16 + rsub;
+      *(float4 *)(Dp + r * S64_DP + c4) = d;
+      *(float4 *)(Ac + r * S64_AP + c4) = av[p];
+      *(float4 *)(Ac + r * S64_AP + 64 + c4) = xv[p];
+    }
+    if (t < 64) sc[t] = scv;
     __syncthreads();
+    if (tile + gridDim.x < ntiles) fetch((tile + gridDim.x) * 64);
     // ---- dX
     f32x16 a0, a1;
 #pragma unroll
@@ -780,7 +808,7 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
 }
 
 constexpr int S64_GRID = 256 * 3;   // persistent workgroups (3 per CU fit LDS)
-constexpr int S64_BWD_GRID = 256 * 3;
+constexpr int S64_BWD_GRID = 256 * 2;
 
 // =============================================================================== VALU
 // small-K forward (2*Fi <= 16, Fo <= 64): wave per row, lane = output column, weights in
@@ -1319,8 +1347,10 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
                          fi, fo, wp);
       int grid = nslab < S64_BWD_GRID ? nslab : S64_BWD_GRID;
       const float ik = epilogue == GSAGE_EPI_RELU_DROPOUT ? 1.0f / (1.0f - p) : 1.0f;
-      hipLaunchKernelGGL(bwd64_fused_k, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x,
-                         wp, agg_scale, N, epilogue, ik, grad_agg, grad_x, slabs);
+      auto kern = epilogue == GSAGE_EPI_NONE ? bwd64_fused_k<0>
+                  : epilogue == GSAGE_EPI_L2NORM ? bwd64_fused_k<2> : bwd64_fused_k<1>;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x,
+                         wp, agg_scale, N, ik, grad_agg, grad_x, slabs);
       GSAGE_CHECK_LAUNCH();
       hipLaunchKernelGGL(reduce_slabs_k, dim3((unsigned)((2 * Fi * Fo + Fo + 63) / 64)), dim3(256), 0,
                          st, slabs, grid, fi, fo, grad_w_l, grad_w_r, grad_b);
