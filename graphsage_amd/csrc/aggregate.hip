@@ -18,6 +18,9 @@
 namespace {
 
 constexpr int AGG_BLOCK = 256;         // 4 waves, one row per wave per iteration
+#ifndef GATHER_NB
+#define GATHER_NB 4
+#endif
 constexpr int HUB_BLOCKS = 256;        // leading workgroups that walk the hub-row list
 
 template <int LPR>
@@ -41,6 +44,7 @@ __device__ __forceinline__ float4 gather_range(const int *__restrict__ col,
                                                const float *__restrict__ ew, int64_t F,
                                                int p0, int p1) {
   constexpr int G = 64 / LPR;
+  constexpr int NB = GATHER_NB;
   const int lane = gs_lane();
   const int slot = lane / LPR, sub = lane % LPR;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -50,46 +54,33 @@ __device__ __forceinline__ float4 gather_range(const int *__restrict__ col,
     int cnt = p1 - pc;
     if (cnt > 64) cnt = 64;
     int steps = (cnt + G - 1) / G;
-    int s = 0;
-    // 4 independent 16-byte loads in flight per lane
-    for (; s + 4 <= steps; s += 4) {
-      int j0 = (s + 0) * G + slot, j1 = (s + 1) * G + slot;
-      int j2 = (s + 2) * G + slot, j3 = (s + 3) * G + slot;
-      int c0 = __shfl(cv, j0, 64), c1 = __shfl(cv, j1, 64);
-      int c2 = __shfl(cv, j2, 64), c3 = __shfl(cv, j3, 64);
-      bool v0 = j0 < cnt, v1 = j1 < cnt, v2 = j2 < cnt, v3 = j3 < cnt;
-      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 r0 = v0 ? *(const float4 *)(x + (int64_t)c0 * F + sub * 4) : z;
-      float4 r1 = v1 ? *(const float4 *)(x + (int64_t)c1 * F + sub * 4) : z;
-      float4 r2 = v2 ? *(const float4 *)(x + (int64_t)c2 * F + sub * 4) : z;
-      float4 r3 = v3 ? *(const float4 *)(x + (int64_t)c3 * F + sub * 4) : z;
-      if (WMODE != 0) {
-        float w0, w1, w2, w3;
-        if (WMODE == 1) {          // weight of the source node
-          w0 = v0 ? ew[c0] : 0.f; w1 = v1 ? ew[c1] : 0.f;
-          w2 = v2 ? ew[c2] : 0.f; w3 = v3 ? ew[c3] : 0.f;
-        } else {                   // weight of the edge (same order as col)
-          w0 = v0 ? ew[pc + j0] : 0.f; w1 = v1 ? ew[pc + j1] : 0.f;
-          w2 = v2 ? ew[pc + j2] : 0.f; w3 = v3 ? ew[pc + j3] : 0.f;
+    // NB independent 16-byte loads in flight per lane; the last batch is predicated rather than
+    // peeled, so a short row (most rows of a power-law graph) still has all its loads in flight.
+    // (plain ifs: a ?: between the loaded lvalue and a zero lvalue becomes a load through a
+    // selected pointer, i.e. flat loads and a zero vector in scratch)
+    for (int s = 0; s < steps; s += NB) {
+      float4 r[NB];
+      float w[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int j = (s + k) * G + slot;
+        const int c = __shfl(cv, j, 64);
+        r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w[k] = 0.f;
+        if (j < cnt) {
+          r[k] = *(const float4 *)(x + (int64_t)c * F + sub * 4);
+          if (WMODE == 1) w[k] = ew[c];        // weight of the source node
+          if (WMODE == 2) w[k] = ew[pc + j];   // weight of the edge (same order as col)
         }
-        acc.x += r0.x * w0; acc.y += r0.y * w0; acc.z += r0.z * w0; acc.w += r0.w * w0;
-        acc.x += r1.x * w1; acc.y += r1.y * w1; acc.z += r1.z * w1; acc.w += r1.w * w1;
-        acc.x += r2.x * w2; acc.y += r2.y * w2; acc.z += r2.z * w2; acc.w += r2.w * w2;
-        acc.x += r3.x * w3; acc.y += r3.y * w3; acc.z += r3.z * w3; acc.w += r3.w * w3;
-      } else {
-        acc.x += r0.x; acc.y += r0.y; acc.z += r0.z; acc.w += r0.w;
-        acc.x += r1.x; acc.y += r1.y; acc.z += r1.z; acc.w += r1.w;
-        acc.x += r2.x; acc.y += r2.y; acc.z += r2.z; acc.w += r2.w;
-        acc.x += r3.x; acc.y += r3.y; acc.z += r3.z; acc.w += r3.w;
       }
-    }
-    for (; s < steps; ++s) {
-      int j = s * G + slot;
-      int c = __shfl(cv, j, 64);
-      if (j < cnt) {
-        float4 r = *(const float4 *)(x + (int64_t)c * F + sub * 4);
-        float w = WMODE == 1 ? ew[c] : WMODE == 2 ? ew[pc + j] : 1.f;
-        acc.x += r.x * w; acc.y += r.y * w; acc.z += r.z * w; acc.w += r.w * w;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        if (WMODE != 0) {
+          acc.x += r[k].x * w[k]; acc.y += r[k].y * w[k];
+          acc.z += r[k].z * w[k]; acc.w += r[k].w * w[k];
+        } else {
+          acc.x += r[k].x; acc.y += r[k].y; acc.z += r[k].z; acc.w += r[k].w;
+        }
       }
     }
   }
