@@ -87,6 +87,11 @@ struct GemmArgs {
   EpiArgs epi;
 };
 
+// staging registers use the native vector type: a float4 (struct) that is only copied in and
+// out becomes a memcpy pair through a private array, i.e. scratch traffic plus a wait on the
+// prefetch right behind its loads
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
 constexpr int G_BK = 32;
 constexpr int G_PITCH = G_BK + 4;
 
@@ -118,8 +123,9 @@ __global__ void __launch_bounds__(256) gemm_rows_k(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[NA], rb[NB];
-  auto gload = [&](int kc) {
+  float4 ra[NA];
+  f32x4v rb[NB];
+  auto gload = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int f = t + i * 256;
@@ -137,10 +143,10 @@ __global__ void __launch_bounds__(256) gemm_rows_k(GemmArgs a) {
     for (int i = 0; i < NB; ++i) {
       int f = t + i * 256;
       int n = f >> 3, c4 = f & 7;
-      rb[i] = *(const float4 *)(a.Bp + (int64_t)(n0 + n) * K + kc + c4 * 4);
+      rb[i] = *(const f32x4v *)(a.Bp + (int64_t)(n0 + n) * K + kc + c4 * 4);
     }
   };
-  auto sstore = [&]() {
+  auto sstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int f = t + i * 256;
@@ -149,7 +155,7 @@ __global__ void __launch_bounds__(256) gemm_rows_k(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int f = t + i * 256;
-      *(float4 *)(Bs + (f >> 3) * G_PITCH + (f & 7) * 4) = rb[i];
+      *(f32x4v *)(Bs + (f >> 3) * G_PITCH + (f & 7) * 4) = rb[i];
     }
   };
 
@@ -292,52 +298,50 @@ __global__ void __launch_bounds__(512, 4) gemm_wide_k(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[NA], rb[NB];
-  auto gload = [&](int kc) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      int f = t + i * 512;
-      int r = f >> 3, c4 = f & 7;
-      int64_t grow = row0 + r;
-      int k = kc + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (grow < a.M) {
-        const float *src = (k < K1) ? a.A1 + grow * K1 + k : a.A2 + grow * K2 + (k - K1);
-        v = *(const float4 *)src;
-      }
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      int f = t + i * 512;
-      rb[i] = *(const float4 *)(a.Bp + (int64_t)(n0 + (f >> 3)) * K + kc + (f & 7) * 4);
-    }
-  };
-  auto sstore = [&](int stage) {
-    float *As = wide_smem + stage * STAGE, *Bs = As + BM * G_PITCH;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      int f = t + i * 512;
-      *(float4 *)(As + (f >> 3) * G_PITCH + (f & 7) * 4) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      int f = t + i * 512;
-      *(float4 *)(Bs + (f >> 3) * G_PITCH + (f & 7) * 4) = rb[i];
-    }
-  };
+  // (macros, not lambdas: with the staging registers captured by a lambda they were kept in
+  // scratch, which also put a wait on the prefetch right behind its loads)
+  float4 ra[NA];
+  f32x4v rb[NB];
+#define WIDE_GLOAD(KC)                                                                        \
+  {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                          \
+      int f = t + i * 512;                                                                    \
+      int64_t grow = row0 + (f >> 3);                                                         \
+      int k = (KC) + (f & 7) * 4;                                                             \
+      bool in = grow < a.M;                                                                   \
+      grow = in ? grow : 0;                                                                   \
+      const float *src = (k < K1) ? a.A1 + grow * K1 + k : a.A2 + grow * K2 + (k - K1);       \
+      ra[i] = *(const float4 *)src;                                                           \
+      if (!in) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                       \
+    }                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                          \
+      int f = t + i * 512;                                                                    \
+      rb[i] = *(const f32x4v *)(a.Bp + (int64_t)(n0 + (f >> 3)) * K + (KC) + (f & 7) * 4);   \
+    }                                                                                         \
+  }
+#define WIDE_SSTORE()                                                                         \
+  {                                                                                           \
+    float *As_ = wide_smem, *Bs_ = As_ + BM * G_PITCH;                                        \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                          \
+      int f = t + i * 512;                                                                    \
+      *(float4 *)(As_ + (f >> 3) * G_PITCH + (f & 7) * 4) = ra[i];                            \
+    }                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                          \
+      int f = t + i * 512;                                                                    \
+      *(f32x4v *)(Bs_ + (f >> 3) * G_PITCH + (f & 7) * 4) = rb[i];                            \
+    }                                                                                         \
+  }
 
   // chunk k+1 travels global -> registers during chunk k's MFMAs.  One LDS stage and two
   // workgroups per CU measured faster (27.6 ms per 256->256 layer at 10 M rows) than two
   // stages with one barrier per chunk but a single workgroup per CU (29.0 ms).
-  gload(0);
-  sstore(0);
+  WIDE_GLOAD(0)
+  WIDE_SSTORE()
   __syncthreads();
-  constexpr int stage = 0;
   for (int kc = 0; kc < K; kc += G_BK) {
     const bool more = kc + G_BK < K;
-    if (more) gload(kc + G_BK);
-    const float *As = wide_smem + stage * STAGE, *Bs = As + BM * G_PITCH;
+    if (more) WIDE_GLOAD(kc + G_BK)
+    const float *As = wide_smem, *Bs = As + BM * G_PITCH;
 #pragma unroll
     for (int g = 0; g < G_BK / 8; ++g) {
       float4 af[TM], bf[TN];
@@ -358,9 +362,11 @@ __global__ void __launch_bounds__(512, 4) gemm_wide_k(GemmArgs a) {
                                                              acc[i][j], 0, 0, 0);
     }
     __syncthreads();
-    if (more) sstore(0);
+    if (more) WIDE_SSTORE()
     __syncthreads();
   }
+#undef WIDE_GLOAD
+#undef WIDE_SSTORE
 
   // ---- epilogue on the accumulators: acc[i][j][r] is row wm*64+i*32+(r&3)+8(r>>2)+4(lane>>5),
   //      column (wn*TN+j)*32 + (lane&31) of the tile
@@ -708,7 +714,7 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
   // tile i's operands reach LDS and complete underneath tile i's MFMAs
   float4 gv[4], yv[4], av[4], xv[4];
   float rn[4], scv = 1.f;
-  auto fetch = [&](int64_t row0) {
+  auto fetch = [&](int64_t row0) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       int64_t row = row0 + p * 16 + rsub;
