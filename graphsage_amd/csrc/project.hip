@@ -685,59 +685,62 @@ proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
 //   dW += dpre^T . [agg | x], db += colsum     (MFMA over the row index, kept in registers
 //                                               across the workgroup's tiles -> one slab)
 template <int MODE>   // 0 = no epilogue, 1 = ReLU(+dropout), 2 = L2 normalisation
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)
 bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
               const float *__restrict__ rnorm, const float *__restrict__ agg,
               const float *__restrict__ x, const float *__restrict__ bp /* [128][64] */,
               const float *__restrict__ agg_scale, int64_t M, float inv_keep,
               float *__restrict__ grad_agg, float *__restrict__ grad_x,
               float *__restrict__ slabs) {
-  __shared__ __align__(16) float Ac[64 * S64_AP];
-  __shared__ __align__(16) float Dp[64 * S64_DP];
-  __shared__ float sc[64];
+  // 32-row tiles, both LDS tiles double-buffered: one barrier per tile, 51 KB per workgroup and
+  // <= 168 VGPRs, so three workgroups share a CU and their MFMA phases interleave
+  constexpr int TR = 32;
+  __shared__ __align__(16) float Ac[2][TR * S64_AP];
+  __shared__ __align__(16) float Dp[2][TR * S64_DP];
+  __shared__ float sc[2][TR];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int rt = w & 1, cp = w >> 1;   // dX: row tile rt, column tiles 2cp, 2cp+1
-  float4 breg[2][8];
+  // dX: wave w owns output columns 32w..32w+31 of [grad_agg | grad_x] for all 32 rows
+  float4 breg[8];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int gi = 0; gi < 8; ++gi)
-      breg[j][gi] = *(const float4 *)(bp + ((2 * cp + j) * 32 + (lane & 31)) * 64 + gi * 8 +
-                                      (lane >> 5) * 4);
+  for (int gi = 0; gi < 8; ++gi)
+    breg[gi] = *(const float4 *)(bp + (w * 32 + (lane & 31)) * 64 + gi * 8 + (lane >> 5) * 4);
   f32x16 dw0, dw1;   // dW tiles: rows m = 0..31 / 32..63, columns 32w .. 32w+31 of [agg | x]
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; }
   float bsum = 0.f;
   const int rsub = t >> 4, c4 = (t & 15) * 4;
-  const int64_t ntiles = (M + 63) / 64;
+  const int64_t ntiles = (M + TR - 1) / TR;
   // the tile's operands travel through registers: the loads of tile i+1 are issued right after
   // tile i's operands reach LDS and complete underneath tile i's MFMAs
-  float4 gv[4], yv[4], av[4], xv[4];
-  float rn[4], scv = 1.f;
-  auto fetch = [&](int64_t row0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      int64_t row = row0 + p * 16 + rsub;
-      if (row < M) {
-        gv[p] = *(const float4 *)(g + row * 64 + c4);
-        if (MODE != 0) yv[p] = *(const float4 *)(y + row * 64 + c4);
-        if (MODE == 2) rn[p] = rnorm[row];
-        av[p] = *(const float4 *)(agg + row * 64 + c4);
-        xv[p] = *(const float4 *)(x + row * 64 + c4);
-      } else {
-        gv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        yv[p] = gv[p]; av[p] = gv[p]; xv[p] = gv[p];
-        rn[p] = 0.f;
-      }
-    }
-    if (t < 64) scv = (agg_scale && row0 + t < M) ? agg_scale[row0 + t] : 1.f;
-  };
-  if ((int64_t)blockIdx.x < ntiles) fetch((int64_t)blockIdx.x * 64);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t row0 = tile * 64;
+  float4 gv[2], yv[2], av[2], xv[2];
+  float rn[2], scv = 1.f;
+#define BWD64_FETCH(ROW0)                                                          \
+  {                                                                                \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                \
+      int64_t row = (ROW0) + p * 16 + rsub;                                        \
+      const bool in = row < M;                                                     \
+      row = in ? row : 0;                                                          \
+      gv[p] = *(const float4 *)(g + row * 64 + c4);                                \
+      if (MODE != 0) yv[p] = *(const float4 *)(y + row * 64 + c4);                 \
+      if (MODE == 2) rn[p] = rnorm[row];                                           \
+      av[p] = *(const float4 *)(agg + row * 64 + c4);                              \
+      xv[p] = *(const float4 *)(x + row * 64 + c4);                                \
+      if (!in) {                                                                   \
+        gv[p] = make_float4(0.f, 0.f, 0.f, 0.f);                                   \
+        yv[p] = gv[p]; av[p] = gv[p]; xv[p] = gv[p];                               \
+        rn[p] = 0.f;                                                               \
+      }                                                                            \
+    }                                                                              \
+    if (t < TR) scv = (agg_scale && (ROW0) + t < M) ? agg_scale[(ROW0) + t] : 1.f; \
+  }
+  if ((int64_t)blockIdx.x < ntiles) BWD64_FETCH((int64_t)blockIdx.x * TR)
+  int buf = 0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    const int64_t row0 = tile * TR;
+    float *Dpb = Dp[buf], *Acb = Ac[buf];
     // ---- dpre tile and [agg | x] tile into LDS
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < 2; ++p) {
       float4 d = gv[p];
       if (MODE == 2) {
         float dot = gv[p].x * yv[p].x + gv[p].y * yv[p].y + gv[p].z * yv[p].z + gv[p].w * yv[p].w;
@@ -750,58 +753,54 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
         d.x = yv[p].x > 0.f ? d.x * inv_keep : 0.f; d.y = yv[p].y > 0.f ? d.y * inv_keep : 0.f;
         d.z = yv[p].z > 0.f ? d.z * inv_keep : 0.f; d.w = yv[p].w > 0.f ? d.w * inv_keep : 0.f;
       }
-      int r = p * 16 + rsub;
-      *(float4 *)(Dp + r * S64_DP + c4) = d;
-      *(float4 *)(Ac + r * S64_AP + c4) = av[p];
-      *(float4 *)(Ac + r * S64_AP + 64 + c4) = xv[p];
+      const int r = p * 16 + rsub;
+      *(float4 *)(Dpb + r * S64_DP + c4) = d;
+      *(float4 *)(Acb + r * S64_AP + c4) = av[p];
+      *(float4 *)(Acb + r * S64_AP + 64 + c4) = xv[p];
     }
-    if (t < 64) sc[t] = scv;
+    if (t < TR) sc[buf][t] = scv;
+    // the only barrier of the tile: the other buffer was last read before every wave reached
+    // the previous one, so the next tile may be staged into it without a second barrier
     __syncthreads();
-    if (tile + gridDim.x < ntiles) fetch((tile + gridDim.x) * 64);
-    // ---- dX
-    f32x16 a0, a1;
+    if (tile + gridDim.x < ntiles) BWD64_FETCH((tile + gridDim.x) * TR)
+    // ---- dX (K = 64 dpre columns) and dW (K = the tile's 32 rows), interleaved
+    f32x16 a0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
-    const float *drow = Dp + (rt * 32 + (lane & 31)) * S64_DP + (lane >> 5) * 4;
+    for (int r = 0; r < 16; ++r) a0[r] = 0.f;
+    const float *drow = Dpb + (lane & 31) * S64_DP + (lane >> 5) * 4;
 #pragma unroll
     for (int gi = 0; gi < 8; ++gi) {
-      float4 af = *(const float4 *)(drow + gi * 8);
+      const float4 af = *(const float4 *)(drow + gi * 8);
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af, s2), f4c(breg[0][gi], s2), a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af, s2), f4c(breg[1][gi], s2), a1, 0, 0, 0);
-      }
-    }
-    // ---- dW (row index = MFMA K)
-#pragma unroll 8
-    for (int kk = 0; kk < 32; ++kk) {
-      int kr = 2 * kk + (lane >> 5);
-      float d0 = Dp[kr * S64_DP + (lane & 31)];
-      float d1 = Dp[kr * S64_DP + 32 + (lane & 31)];
-      float b = Ac[kr * S64_AP + w * 32 + (lane & 31)];
-      dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, b, dw0, 0, 0, 0);
-      dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, b, dw1, 0, 0, 0);
-    }
-    if (t < 64) {
-#pragma unroll 8
-      for (int k = 0; k < 64; ++k) bsum += Dp[k * S64_DP + t];
-    }
-    // ---- dX stores straight from the accumulators (128-byte row segments)
-    {
-      float *dst = cp == 0 ? grad_agg : grad_x;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int lr = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        int64_t grow = row0 + lr;
-        float s = cp == 0 ? sc[lr] : 1.f;
-        if (grow < M) {
-          dst[grow * 64 + (lane & 31)] = a0[r] * s;
-          dst[grow * 64 + 32 + (lane & 31)] = a1[r] * s;
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af, s2), f4c(breg[gi], s2), a0, 0, 0, 0);
+        if (s2 & 1) {
+          const int kr = 2 * (gi * 2 + (s2 >> 1)) + (lane >> 5);
+          const float d0 = Dpb[kr * S64_DP + (lane & 31)];
+          const float d1 = Dpb[kr * S64_DP + 32 + (lane & 31)];
+          const float b = Acb[kr * S64_AP + w * 32 + (lane & 31)];
+          dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, b, dw0, 0, 0, 0);
+          dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, b, dw1, 0, 0, 0);
         }
       }
     }
-    __syncthreads();   // all reads of Dp / Ac / sc done before the next tile restages them
+    if (t < 64) {
+#pragma unroll 8
+      for (int k = 0; k < TR; ++k) bsum += Dpb[k * S64_DP + t];
+    }
+    // ---- dX stores straight from the accumulators (128-byte row segments)
+    {
+      float *dst = (w < 2 ? grad_agg : grad_x) + (w & 1) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int64_t grow = row0 + lr;
+        const float s = w < 2 ? sc[buf][lr] : 1.f;
+        if (grow < M) dst[grow * 64] = a0[r] * s;
+      }
+    }
   }
+#undef BWD64_FETCH
   float *slab = slabs + (int64_t)blockIdx.x * (64 * 128 + 64);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -814,7 +813,7 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
 }
 
 constexpr int S64_GRID = 256 * 3;   // persistent workgroups (3 per CU fit LDS)
-constexpr int S64_BWD_GRID = 256 * 2;
+constexpr int S64_BWD_GRID = 256 * 3;
 
 // =============================================================================== VALU
 // small-K forward (2*Fi <= 16, Fo <= 64): wave per row, lane = output column, weights in
