@@ -871,6 +871,9 @@ __global__ void __launch_bounds__(256)
 project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
                   const float *__restrict__ wt /* [16][Fo] */, int64_t N, int Fo, EpiArgs e,
                   float *__restrict__ out) {
+  constexpr int K16_PP = 68;                   // pitch of the 16 x 64 output patch
+  __shared__ __align__(16) float patches[4][16 * K16_PP];
+  float *patch = patches[threadIdx.x >> 6];
   const int lane = gs_lane();
   const int rl = lane & 15, q = lane >> 4;
   const int cb = blockIdx.y * 64;              // this workgroup's 64 output columns
@@ -933,9 +936,18 @@ project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
       for (int nt = 0; nt < 4; ++nt) { v[nt].x *= rn; v[nt].y *= rn; v[nt].z *= rn; v[nt].w *= rn; }
       if (live && q == 0 && e.rnorm) e.rnorm[row] = rn;
     }
-    if (live) {
+    // a lane holds 16-byte pieces of 4 different 64-byte chunks of its row; stored like that
+    // every store instruction writes sixteen 64-byte chunks and the kernel runs at 3.6 TB/s
+    // (tools/micro/streambench v4).  Through a wave-private LDS patch each store instruction
+    // covers 4 whole 256-byte row segments instead (v4b: 4.9 TB/s).
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) *(float4 *)(out + row * Fo + cb + 16 * nt + 4 * q) = v[nt];
+    for (int nt = 0; nt < 4; ++nt) *(float4 *)(patch + rl * K16_PP + 16 * nt + 4 * q) = v[nt];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = 4 * i + q;                       // q = lane >> 4: 4 rows per instruction
+      const int64_t orow = r0 + rr;
+      const float4 o = *(const float4 *)(patch + rr * K16_PP + rl * 4);
+      if (orow < N) *(float4 *)(out + orow * Fo + cb + rl * 4) = o;
     }
   }
 }
