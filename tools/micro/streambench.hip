@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(256) v4b(const float *a8, float *c, long M) {
   }
 }
 
+template <int CONTIG>
 __global__ void __launch_bounds__(256)
 v5(const float *a, const float *b, const float *c, const float *d, float *o1, float *o2, long M) {
   __shared__ __align__(16) float T[2][32 * 68];
@@ -106,8 +107,12 @@ v5(const float *a, const float *b, const float *c, const float *d, float *o1, fl
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int p = 0; p < 2; ++p)
-      r[s][p] = *(const float4 *)(src[s] + ((long)blockIdx.x * 32 + p * 16 + rsub) * 64 + c4);
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      r[s][p] = *(const float4 *)(src[s] + ((CONTIG ? (long)blockIdx.x * ((ntiles + gridDim.x - 1) / gridDim.x) : (long)blockIdx.x) * 32 + p * 16 + rsub) * 64 + c4);
+  const long per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const long t_begin = CONTIG ? (long)blockIdx.x * per : (long)blockIdx.x;
+  const long t_end = CONTIG ? (t_begin + per < ntiles ? t_begin + per : ntiles) : ntiles;
+  const long t_step = CONTIG ? 1 : (long)gridDim.x;
+  for (long tile = t_begin; tile < t_end; tile += t_step) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       *(float4 *)(T[0] + (p * 16 + rsub) * 68 + c4) =
@@ -116,8 +121,8 @@ v5(const float *a, const float *b, const float *c, const float *d, float *o1, fl
           make_float4(r[2][p].x + r[3][p].x, r[2][p].y + r[3][p].y, r[2][p].z + r[3][p].z, r[2][p].w + r[3][p].w);
     }
     __syncthreads();
-    long nt = tile + gridDim.x;
-    if (nt < ntiles) {
+    long nt = tile + t_step;
+    if (nt < t_end) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -166,7 +171,9 @@ int main(int argc, char **argv) {
   for (int grid : {512, 768, 1536})  {
     char nm[96];
     snprintf(nm, 96, "v5 4 in / 2 out tiled, %d blocks", grid);
-    run(nm, 6 * g1, [&] { v5<<<grid, 256>>>(buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], M); });
+    run(nm, 6 * g1, [&] { v5<0><<<grid, 256>>>(buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], M); });
+    snprintf(nm, 96, "v5c same, contiguous tile ranges, %d blocks", grid);
+    run(nm, 6 * g1, [&] { v5<1><<<grid, 256>>>(buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], M); });
   }
   return 0;
 }
