@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import EPI_L2NORM, EPI_NONE, EPI_RELU, EPI_RELU_DROPOUT
+from ._lib import EPI_L2NORM, EPI_NONE
 from .graph import GraphCSR
 
 

@@ -30,8 +30,7 @@ the hand-computed known-answer tests in ``oracle/kat.py`` instead.
 """
 from __future__ import annotations
 
-import math
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch

@@ -3,7 +3,6 @@ golden tables produced with the reference's own src/walks code (tests/golden/ali
 import os
 
 import numpy as np
-import pytest
 import torch
 
 from oracle import sage_oracle as O

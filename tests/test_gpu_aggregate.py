@@ -1,5 +1,4 @@
 """GPU: K2 / K7 segment gather vs the oracle's index_select + scatter_add_ mean."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,7 +1,5 @@
 """GPU: training harness: epoch means vs the oracle on injected batches, the
 captured-HIP-graph step vs the eager step, checkpoints interchangeable with plain torch Adam."""
-import os
-
 import pytest
 import torch
 

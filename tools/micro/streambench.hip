@@ -157,6 +157,9 @@ int main(int argc, char **argv) {
   };
   const double g1 = bytes / 1e9;
   run("v1 elementwise 2r:1w grid-stride 16384 blocks", 3 * g1, [&] { v1<<<16384, 256>>>((float4 *)buf[0], (float4 *)buf[1], (float4 *)buf[2], (size_t)M * 16); });
+  run("v1 elementwise 2r:1w, 65536 blocks", 3 * g1, [&] { v1<<<65536, 256>>>((float4 *)buf[0], (float4 *)buf[1], (float4 *)buf[2], (size_t)M * 16); });
+  run("v1 elementwise 2r:1w, one float4 per thread (625000 blocks)", 3 * g1, [&] { v1<<<625000, 256>>>((float4 *)buf[0], (float4 *)buf[1], (float4 *)buf[2], (size_t)M * 16); });
+  run("v1 elementwise 2r:1w, 2048 blocks", 3 * g1, [&] { v1<<<2048, 256>>>((float4 *)buf[0], (float4 *)buf[1], (float4 *)buf[2], (size_t)M * 16); });
   for (int grid : {512, 768, 1024, 2048}) {
     char nm[96];
     snprintf(nm, 96, "v2 tiled float4 stores, %d persistent blocks", grid);
@@ -168,6 +171,10 @@ int main(int argc, char **argv) {
   run("v4 narrow read, 64B-chunk stores, 16384 blocks", 1.125 * g1, [&] { v4<<<16384, 256>>>(buf[0], buf[2], M); });
   run("v4b narrow read, whole-row stores via LDS, 2048 blocks", 1.125 * g1, [&] { v4b<<<2048, 256>>>(buf[0], buf[2], M); });
   run("v4b narrow read, whole-row stores via LDS, 8192 blocks", 1.125 * g1, [&] { v4b<<<8192, 256>>>(buf[0], buf[2], M); });
+  run("v2 tiled float4 stores, one tile per block (312500 blocks)", 3 * g1, [&] { v2<0><<<312500, 256>>>(buf[0], buf[1], buf[2], M); });
+  run("v5 4 in / 2 out, one tile per block (312500 blocks)", 6 * g1, [&] { v5<0><<<312500, 256>>>(buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], M); });
+  run("v5 4 in / 2 out, 16384 blocks", 6 * g1, [&] { v5<0><<<16384, 256>>>(buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], M); });
+  run("v5c contiguous ranges, 16384 blocks", 6 * g1, [&] { v5<1><<<16384, 256>>>(buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], M); });
   for (int grid : {512, 768, 1536})  {
     char nm[96];
     snprintf(nm, 96, "v5 4 in / 2 out tiled, %d blocks", grid);
