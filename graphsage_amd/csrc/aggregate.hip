@@ -237,7 +237,9 @@ int launch_vec(const int *rowptr, const int *col, const float *row_scale, const 
   const bool hubs = long_rows && n_long;
   const int long_t = hubs ? gsage_long_row_threshold() : 0;
   const int hub_blocks = hubs ? HUB_BLOCKS : 0;
-  const int grid = gs_grid(N, (AGG_BLOCK / 64) * G, 256 * 64) + hub_blocks;
+  // one trip per wave: with workgroups dispatched in order the chip works on a compact window of
+  // rowptr/col/out, which measured 4.5 % faster than a 16384-workgroup grid-stride loop
+  const int grid = gs_grid(N, (AGG_BLOCK / 64) * G, 1 << 22) + hub_blocks;
   if (ew && per_edge)
     hipLaunchKernelGGL((seg_gather_vec_k<LPR, 2>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr,
                        col, row_scale, ew, x, add_to, N, F, out, long_t, long_rows, n_long,

@@ -16,6 +16,23 @@ __global__ void __launch_bounds__(256) v1(const float4 *a, const float4 *b, floa
   }
 }
 
+// v0: read-only (sum kept in a register, one conditional store so the loads stay)
+template <int UNROLL>
+__global__ void __launch_bounds__(256) v0(const float4 *a, float *out, size_t n4) {
+  float acc = 0.f;
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+    float4 x[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) x[u] = a[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc += x[u].x + x[u].y + x[u].z + x[u].w;
+  }
+  for (; i < n4; i += stride) { float4 x = a[i]; acc += x.x + x.y + x.z + x.w; }
+  if (acc == 123.456f) out[0] = acc;
+}
+
 template <int STORE>
 __global__ void __launch_bounds__(256) v2(const float *a, const float *b, float *c, long M) {
   __shared__ __align__(16) float T[32 * 68];
@@ -156,6 +173,10 @@ int main(int argc, char **argv) {
     printf("%-44s %7.3f ms  %6.2f TB/s\n", name, ms, gb / ms);
   };
   const double g1 = bytes / 1e9;
+  run("v0 read-only, 4 loads in flight, 2048 blocks", g1, [&] { v0<4><<<2048, 256>>>((float4 *)buf[0], buf[5], (size_t)M * 16); });
+  run("v0 read-only, 4 loads in flight, 16384 blocks", g1, [&] { v0<4><<<16384, 256>>>((float4 *)buf[0], buf[5], (size_t)M * 16); });
+  run("v0 read-only, 1 load per thread (625000 blocks)", g1, [&] { v0<1><<<625000, 256>>>((float4 *)buf[0], buf[5], (size_t)M * 16); });
+  run("v0 read-only, 8 loads in flight, 4096 blocks", g1, [&] { v0<8><<<4096, 256>>>((float4 *)buf[0], buf[5], (size_t)M * 16); });
   run("v1 elementwise 2r:1w grid-stride 16384 blocks", 3 * g1, [&] { v1<<<16384, 256>>>((float4 *)buf[0], (float4 *)buf[1], (float4 *)buf[2], (size_t)M * 16); });
   run("v1 elementwise 2r:1w, 65536 blocks", 3 * g1, [&] { v1<<<65536, 256>>>((float4 *)buf[0], (float4 *)buf[1], (float4 *)buf[2], (size_t)M * 16); });
   run("v1 elementwise 2r:1w, one float4 per thread (625000 blocks)", 3 * g1, [&] { v1<<<625000, 256>>>((float4 *)buf[0], (float4 *)buf[1], (float4 *)buf[2], (size_t)M * 16); });
