@@ -561,31 +561,6 @@ dw_mfma_k(const float *__restrict__ dpre, const float *__restrict__ agg,
 constexpr int S64_AP = 132;   // pitch of the [agg | x] tile (128 columns)
 constexpr int S64_DP = 68;    // pitch of a 64-column tile
 
-// stage rows [row0, row0+64) of [a1 | a2] (64 columns each) into tile[64][S64_AP]
-__device__ __forceinline__ void s64_stage_cat(const float *__restrict__ a1,
-                                              const float *__restrict__ a2, int64_t row0,
-                                              int64_t M, float *tile) {
-  const int t = threadIdx.x;
-  float4 r1[4], r2[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    int64_t row = row0 + p * 16 + (t >> 4);
-    int c = (t & 15) * 4;
-    if (row < M) {
-      r1[p] = *(const float4 *)(a1 + row * 64 + c);
-      r2[p] = *(const float4 *)(a2 + row * 64 + c);
-    } else {
-      r1[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      r2[p] = r1[p];
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    int r = p * 16 + (t >> 4), c = (t & 15) * 4;
-    *(float4 *)(tile + r * S64_AP + c) = r1[p];
-    *(float4 *)(tile + r * S64_AP + 64 + c) = r2[p];
-  }
-}
 
 __global__ void __launch_bounds__(256, 2)
 proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
