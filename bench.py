@@ -218,7 +218,8 @@ def main():
             "config": {"workload": desc, "nodes": nodes, "edges": E, "negatives": K,
                        "pairs_per_gpu": B, "global_batch": B * world, "dropout": args.dropout,
                        "parallelism": f"replicated graph, pair-sharded dp{world}",
-                       "loss_backward": "deterministic" if ops.LOSS_BWD_DETERMINISTIC else "atomic",
+                       "loss_backward": "deterministic (sorted)" if ops.loss_bwd_deterministic(nodes, B, K)
+                       else "atomic",
                        "final_loss": loss},
             "roofline": roofline, "cpu_baseline": cpu,
         }), flush=True)

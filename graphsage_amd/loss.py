@@ -23,7 +23,8 @@ class SkipGramLoss(nn.Module):
 
     def __init__(self, scale_factor: float = 5.0, deterministic: Optional[bool] = None):
         """``deterministic``: True = sort-based backward (bitwise reproducible gradients),
-        False = float-atomic scatter (fastest), None = follow GSAGE_LOSS_BWD (default atomic)."""
+        False = float-atomic scatter, None = follow GSAGE_LOSS_BWD (default auto: whichever is
+        faster for the batch and table size, see ops.loss_bwd_deterministic)."""
         super().__init__()
         self.scale_factor = scale_factor
         self.deterministic = deterministic

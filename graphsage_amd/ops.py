@@ -171,10 +171,23 @@ def skipgram_fwd(emb, targets, contexts, negatives, scale, norm_b=None, norm_bk=
     return coef, stats
 
 
-# Loss backward: float-atomic scatter by default (fastest: 2.05 ms at C4/B=2^20 incl. zero-fill);
-# GSAGE_LOSS_BWD=det or SkipGramLoss(deterministic=True) selects the sort-based form (3.9 ms,
-# bitwise reproducible).  Same values up to summation order.
-LOSS_BWD_DETERMINISTIC = os.environ.get("GSAGE_LOSS_BWD", "atomic") == "det"
+# Loss backward: a float-atomic scatter, or the sort-based form (bitwise reproducible, no
+# zero-fill).  Same values up to summation order.  Which is faster depends on how many of the
+# 2(1+K)B terms land on each of the N rows: at B = 2^20, K = 5 the sorted form wins at 100 k and
+# 1 M nodes (3.0 vs 3.35 and 10.1 vs 10.9 ms per step) and loses at 10 M (31.9 vs 30.1), and for
+# small batches its dozen launches cost more than they save.  GSAGE_LOSS_BWD=atomic|det forces
+# one, SkipGramLoss(deterministic=True/False) does the same per module; default "auto".
+LOSS_BWD_MODE = os.environ.get("GSAGE_LOSS_BWD", "auto")
+if LOSS_BWD_MODE not in ("auto", "atomic", "det"):
+    raise ValueError(f"GSAGE_LOSS_BWD must be auto, atomic or det, not {LOSS_BWD_MODE!r}")
+
+
+def loss_bwd_deterministic(N: int, B: int, K: int) -> bool:
+    """The form skipgram_bwd takes when the caller does not say."""
+    if LOSS_BWD_MODE != "auto":
+        return LOSS_BWD_MODE == "det"
+    terms = 2 * (1 + K) * B
+    return terms >= (1 << 20) and terms >= 4 * N
 
 
 def skipgram_bwd(emb, targets, contexts, negatives, coef, grad_loss, grad_emb=None,
@@ -184,7 +197,7 @@ def skipgram_bwd(emb, targets, contexts, negatives, coef, grad_loss, grad_emb=No
     B = targets.numel()
     K = coef.shape[1] - 1
     if deterministic is None:
-        deterministic = LOSS_BWD_DETERMINISTIC
+        deterministic = loss_bwd_deterministic(N, B, K)
     if deterministic and grad_emb is None:
         with torch.cuda.device(emb.device):
             grad_emb = torch.empty_like(emb)
