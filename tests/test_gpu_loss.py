@@ -161,3 +161,46 @@ def test_deterministic_backward_ignores_out_of_range_pairs():
     a = ops.skipgram_bwd(emb, t, c, neg, coef, one, deterministic=False)
     assert torch.isfinite(d).all()
     assert_close(d, a, rtol=1e-5, floor=2e-6)
+
+
+def test_full_size_c4_loss_properties():
+    """BASELINE C4 sizes (10 M x 64 table, 2^20 pairs, K=5), where the oracle cannot run:
+    the two independent backward algorithms agree row for row, the column sums of grad_emb equal
+    the analytic ones (float64 index arithmetic in torch), the loss of the batch is the
+    shard-weighted sum of 8 shard losses, and untouched rows get exactly zero."""
+    from graphsage_amd import ops
+    from graphsage_amd.synth import cooccurrence_batch, powerlaw_graph
+    n, d, b, k = 10_000_000, 64, 1 << 20, 5
+    g = torch.Generator(device="cuda").manual_seed(3)
+    emb = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g), dim=1)
+    ei = powerlaw_graph(1_000_000, 20, seed=5, device="cuda")          # index source only
+    t, c, neg = cooccurrence_batch(ei, 1_000_000, b, k, seed=9)
+    del ei
+    spread = torch.randint(0, 10, (b,), device="cuda", generator=g)    # spread ids over all 10 M rows
+    t, c, neg = t * 10 + spread, c * 10 + spread, neg * 10 + spread.view(-1, 1)
+    coef, stats = ops.skipgram_fwd(emb, t, c, neg, 5.0)
+    assert stats[7].item() == 0 and torch.isfinite(stats[:7]).all()
+    # loss = sum of shard losses normalised by the global batch
+    parts = []
+    for s in range(8):
+        sl = slice(s * b // 8, (s + 1) * b // 8)
+        _, st = ops.skipgram_fwd(emb, t[sl], c[sl], neg[sl], 5.0, norm_b=b, norm_bk=b * k)
+        parts.append(st[0])
+    assert abs(float(torch.stack(parts).sum()) - float(stats[0])) <= 2e-6 * abs(float(stats[0]))
+    one = torch.ones((), device="cuda")
+    atom = ops.skipgram_bwd(emb, t, c, neg, coef, one, deterministic=False)
+    det = ops.skipgram_bwd(emb, t, c, neg, coef, one, deterministic=True)
+    scale = float(det.abs().max())
+    assert float((atom - det).abs().max()) <= 1e-5 * scale
+    touched = torch.zeros(n, dtype=torch.bool, device="cuda")
+    touched[t] = True
+    touched[c] = True
+    touched[neg.reshape(-1)] = True
+    assert float(det[~touched].abs().max()) == 0.0 and float(atom[~touched].abs().max()) == 0.0
+    # analytic column sums: every term coef*emb[src] lands once in grad_emb
+    cf = coef.double()
+    others = torch.cat([c.view(-1, 1), neg], 1)                          # [B, 1+K]
+    want = (cf.unsqueeze(2) * emb[others].double()).sum((0, 1))          # terms added to targets
+    want += (cf.unsqueeze(2) * emb[t].double().unsqueeze(1)).sum((0, 1)) # terms added to c / negatives
+    got = det.double().sum(0)
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
