@@ -365,7 +365,7 @@ extern "C" int gsage_csr_build(const int64_t *edge_index, int64_t E, int64_t N, 
   int bits = 0;
   while ((1ll << bits) <= N) ++bits;  // bits needed to hold the sentinel key N
 
-  if (n_long && hipMemsetAsync(n_long, 0, 2 * sizeof(int32_t), st) != hipSuccess)
+  if (n_long && !gs_zero_async(n_long, 2 * sizeof(int32_t), st))
     return GSAGE_ERR_LAUNCH;
 
   for (int orient = 0; orient < 2; ++orient) {
@@ -373,7 +373,7 @@ extern "C" int gsage_csr_build(const int64_t *edge_index, int64_t E, int64_t N, 
     const int *val = orient == 0 ? src32 : dst32;
     int32_t *rp = orient == 0 ? rowptr : rowptr_t;
     int32_t *cl = orient == 0 ? col : col_t;
-    if (hipMemsetAsync(deg, 0, (size_t)(N + 2) * 4, st) != hipSuccess) return GSAGE_ERR_LAUNCH;
+    if (!gs_zero_async(deg, (size_t)(N + 2) * 4, st)) return GSAGE_ERR_LAUNCH;
     if (E > 0)
       hipLaunchKernelGGL(degree_k, dim3(gs_grid(E, 256)), dim3(256), 0, st, key, E, deg);
     if (orient == 0 && N > 0)

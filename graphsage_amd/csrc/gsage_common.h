@@ -44,3 +44,19 @@ static inline int gs_grid(int64_t work_items, int per_block, int cap = 256 * 8) 
   if (b > cap) b = cap;
   return (int)b;
 }
+
+// Zero `words` 32-bit words with a kernel of our own.  Used instead of hipMemsetAsync wherever a
+// call may be recorded into a HIP graph: a 4-byte memset node in front of the loss kernel was
+// observed to leave a stale word about once in 2 500 replays of a captured training step.
+static __global__ void __launch_bounds__(256) gs_zero_words_k(uint32_t *p, int64_t words) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) p[i] = 0u;
+}
+
+static inline bool gs_zero_async(void *p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return true;
+  const int64_t words = (int64_t)((bytes + 3) / 4);   // buffers here are all 4-byte multiples
+  hipLaunchKernelGGL(gs_zero_words_k, dim3(gs_grid(words, 256 * 4)), dim3(256), 0, st, (uint32_t *)p,
+                     words);
+  return hipGetLastError() == hipSuccess;
+}

@@ -1323,9 +1323,9 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
   const int nslab = num_slabs(N);
 
   if (N == 0) {
-    if (hipMemsetAsync(grad_w_l, 0, (size_t)Fi * Fo * 4, st) != hipSuccess ||
-        hipMemsetAsync(grad_w_r, 0, (size_t)Fi * Fo * 4, st) != hipSuccess ||
-        hipMemsetAsync(grad_b, 0, (size_t)Fo * 4, st) != hipSuccess)
+    if (!gs_zero_async(grad_w_l, (size_t)Fi * Fo * 4, st) ||
+        !gs_zero_async(grad_w_r, (size_t)Fi * Fo * 4, st) ||
+        !gs_zero_async(grad_b, (size_t)Fo * 4, st))
       return GSAGE_ERR_LAUNCH;
     return GSAGE_OK;
   }

@@ -32,19 +32,23 @@ struct SgArgs {
   float scale, invB, invBK;
   float *coef;
   float *partials;  // [gridDim.x][8]
-  int *flag;
 };
 
-__device__ __forceinline__ void sg_block_reduce(float (&st)[SG_NSTAT], float *partials) {
-  __shared__ float red[4][SG_NSTAT];
+// slot 6 of a workgroup's partials carries its "saw an out-of-range id" flag: no shared flag
+// word, so nothing has to be zeroed before the launch (a hipMemsetAsync node in front of the
+// kernel was seen to leave the word stale about once in 2 500 replays of a captured HIP graph)
+__device__ __forceinline__ void sg_block_reduce(float (&st)[SG_NSTAT], bool bad, float *partials) {
+  __shared__ float red[4][SG_NSTAT + 1];
   const int lane = gs_lane(), w = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < SG_NSTAT; ++i) {
     float v = gs_wave_sum(st[i]);
     if (lane == 0) red[w][i] = v;
   }
+  const bool wave_bad = __ballot(bad) != 0ull;
+  if (lane == 0) red[w][SG_NSTAT] = wave_bad ? 1.f : 0.f;
   __syncthreads();
-  if (threadIdx.x < SG_NSTAT)
+  if (threadIdx.x <= SG_NSTAT)
     partials[blockIdx.x * 8 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] +
                                              red[2][threadIdx.x] + red[3][threadIdx.x];
 }
@@ -127,8 +131,7 @@ __global__ void __launch_bounds__(256) skipgram_fwd_vec_k(SgArgs a) {
       }
     }
   }
-  if (bad) atomicOr(a.flag, GSAGE_FLAG_INDEX_OUT_OF_RANGE);
-  sg_block_reduce(st, a.partials);
+  sg_block_reduce(st, bad, a.partials);
 }
 
 // any D: one wavefront per pair, lanes stride the columns
@@ -156,18 +159,17 @@ __global__ void __launch_bounds__(256) skipgram_fwd_generic_k(SgArgs a) {
       }
     }
   }
-  if (bad) atomicOr(a.flag, GSAGE_FLAG_INDEX_OUT_OF_RANGE);
-  sg_block_reduce(st, a.partials);
+  sg_block_reduce(st, bad, a.partials);
 }
 
 // one wavefront: ordered double-precision sum of the per-workgroup partials
 __global__ void __launch_bounds__(64)
 skipgram_finish_k(const float *__restrict__ partials, int nblocks, float invB, float invBK,
-                  const int *__restrict__ flag, float *__restrict__ stats) {
+                  float *__restrict__ stats) {
   const int lane = gs_lane();
-  double s[SG_NSTAT];
+  double s[SG_NSTAT + 1];
 #pragma unroll
-  for (int i = 0; i < SG_NSTAT; ++i) {
+  for (int i = 0; i <= SG_NSTAT; ++i) {
     double v = 0.0;
     for (int b = lane; b < nblocks; b += 64) v += (double)partials[b * 8 + i];
 #pragma unroll
@@ -184,7 +186,7 @@ skipgram_finish_k(const float *__restrict__ partials, int nblocks, float invB, f
     stats[4] = (float)(s[3] * (double)invBK);
     stats[5] = (float)(s[4] * (double)invB);
     stats[6] = (float)(s[5] * (double)invBK);
-    stats[7] = (float)(*flag);
+    stats[7] = s[SG_NSTAT] > 0.0 ? (float)GSAGE_FLAG_INDEX_OUT_OF_RANGE : 0.f;
   }
 }
 
@@ -339,14 +341,12 @@ extern "C" int gsage_skipgram_fwd(const float *emb, int64_t N, int64_t D, const 
   if (ws_bytes < gsage_skipgram_workspace_bytes(B)) return GSAGE_ERR_WORKSPACE;
   hipStream_t st = gs_stream(stream);
   float *partials = (float *)ws;
-  int *flag = (int *)((char *)ws + (size_t)SG_MAX_BLOCKS * 8 * sizeof(float));
-  if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return GSAGE_ERR_LAUNCH;
   SgArgs a;
   a.emb = emb; a.N = N; a.D = D; a.tg = targets; a.ctx = contexts; a.neg = negatives;
   a.B = B; a.K = K; a.scale = scale;
   a.invB = (float)(1.0 / loss_norm_B);
   a.invBK = K > 0 ? (float)(1.0 / loss_norm_BK) : 0.f;
-  a.coef = coef; a.partials = partials; a.flag = flag;
+  a.coef = coef; a.partials = partials;
   int nb;
   const bool vec = (D % 4 == 0) && D <= 256 && (((uintptr_t)emb) & 15) == 0;
   if (vec) {
@@ -360,7 +360,7 @@ extern "C" int gsage_skipgram_fwd(const float *emb, int64_t N, int64_t D, const 
   }
   GSAGE_CHECK_LAUNCH();
   hipLaunchKernelGGL(skipgram_finish_k, dim3(1), dim3(64), 0, st, partials, nb, a.invB, a.invBK,
-                     flag, stats);
+                     stats);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }
@@ -408,8 +408,8 @@ extern "C" int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D,
   float *w = (float *)(b + L.o_w);
   int *longs = (int *)(b + L.o_long), *nlong = (int *)(b + L.o_nlong);
 
-  if (hipMemsetAsync(deg, 0, (size_t)(N + 2) * 4, st) != hipSuccess ||
-      hipMemsetAsync(nlong, 0, 16, st) != hipSuccess)
+  if (!gs_zero_async(deg, (size_t)(N + 2) * 4, st) ||
+      !gs_zero_async(nlong, 16, st))
     return GSAGE_ERR_LAUNCH;
   hipLaunchKernelGGL(sg_terms_k, dim3(gs_grid(L.M, 256)), dim3(256), 0, st, targets, contexts,
                      negatives, B, K, N, key, val, deg);

@@ -101,16 +101,24 @@ class TrainStep:
         return self.flat.extra
 
     # ------------------------------------------------------------- whole step as one HIP graph
-    def capture_step(self, batch_size: int, num_negatives: int, warmup: int = 3) -> None:
+    def capture_step(self, batch_size: int, num_negatives: int, warmup: int = 3,
+                     preserve_state: bool = False) -> None:
         """Capture zero_grad -> forward -> loss -> backward -> clip -> Adam into ONE HIP graph
         for batches of exactly (batch_size, num_negatives).  Worth it when the graph is small
         and the step is launch-bound (the reference's default B = 1024 on its 500-node graph:
         ~60 launches of a few microseconds each).  Dropout masks are then drawn by torch's
         graph-safe Philox generator and handed to the projection kernel as keep-masks (a seed
-        passed by value would be frozen into the graph)."""
+        passed by value would be frozen into the graph).  The warm-up and the capture run real
+        steps on an all-zero batch; ``preserve_state`` puts parameters and Adam state back as
+        they were afterwards (what a trainer wants when it captures in the middle of a run)."""
         if self.world > 1:
             raise RuntimeError("capture_step covers the single-GPU step only")
         dev = self.features.device
+        saved = None
+        if preserve_state:
+            st = self.optimizer.state.get(self.flat.flat_param, {})
+            saved = (self.flat.flat.detach().clone(),
+                     {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)})
         self._gt = torch.zeros(batch_size, dtype=torch.int64, device=dev)
         self._gc = torch.zeros(batch_size, dtype=torch.int64, device=dev)
         self._gn = torch.zeros(batch_size, num_negatives, dtype=torch.int64, device=dev)
@@ -125,6 +133,13 @@ class TrainStep:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._graph_body(batch_size)
+        if saved is not None:
+            with torch.no_grad():
+                self.flat.flat.copy_(saved[0])
+                st = self.optimizer.state.get(self.flat.flat_param, {})
+                for k, v in st.items():
+                    if torch.is_tensor(v):      # in place: the graph holds these addresses
+                        v.copy_(saved[1][k]) if k in saved[1] else v.zero_()
 
     def _graph_body(self, batch_size: int) -> None:
         model = self.model

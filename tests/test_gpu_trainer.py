@@ -63,6 +63,29 @@ def test_epoch_means_match_oracle_on_injected_batches():
         assert_close(pg, pr, rtol=1e-4, floor=2e-5, what=name)
 
 
+def test_trainer_with_and_without_captured_step_agree():
+    """Full batches replayed from one captured HIP graph (the default on small graphs) against
+    the eager step: same epoch means and parameters (dropout 0, so no random stream differs)."""
+    from graphsage_amd import GraphSAGETrainer
+    out = []
+    for hg in (True, False):
+        n, ei, x, t, c, m, _ = _setup()
+        g = torch.Generator().manual_seed(1)
+        negs = [torch.randint(0, n, (2048, 5), generator=g) for _ in range(12)]
+        cfg = {"training": {"batch_size": 1024, "hip_graph": hg}, "negatives": {"per_positive": 5},
+               "validation": {"val_fraction": 0.0}}
+        tr = GraphSAGETrainer(m, x.cuda(), ei.cuda(), (t, c), FixedNegatives(list(negs)), cfg)
+        tr.batch_generator.shuffle = False
+        assert tr._use_graph is hg
+        hist = [tr.train_epoch() for _ in range(3)]
+        out.append((hist, [p.detach().clone() for p in m.parameters()]))
+    for a, b in zip(out[0][0], out[1][0]):
+        for k in a:
+            assert a[k] == pytest.approx(b[k], rel=1e-5), k
+    for pa, pb in zip(out[0][1], out[1][1]):
+        assert_close(pa, pb, rtol=1e-4, floor=2e-5)
+
+
 def test_validate_and_train_loop_and_checkpoint(tmp_path):
     from graphsage_amd import DegreeBiasedNegativeSampler, GraphSAGE, GraphSAGETrainer
     n, ei, x, t, c, m, ref = _setup(dropout=0.3)
