@@ -14,9 +14,15 @@ struct GsSortWs {
 
 // exclusive scan of in[0..n) into out[0..n); in may equal out
 int gs_exclusive_scan(const int *in, int64_t n, int *out, int *bsum, hipStream_t st);
-// stable sort of (keys, vals) by key in [0, 2^bits); the sorted values land in vout_final
+// stable sort of (keys, vals) by key in [0, 2^bits); the sorted values land in vout_final.
+// sorted_keys (optional) receives a pointer to the sorted keys (inside ws, or `keys` when n <= 0)
 int gs_radix_sort_vals(const int *keys, const int *vals, int64_t n, int bits, int *vout_final,
-                       const GsSortWs &ws, hipStream_t st);
+                       const GsSortWs &ws, hipStream_t st, const int **sorted_keys = nullptr);
+// rowptr[0..nrows] from keys sorted ascending in [0, nrows]: rowptr[k] = first position whose key
+// is >= k (so key `nrows`, the sentinel of dropped entries, ends the last real row).  No atomics,
+// no histogram: one streaming pass over the keys.
+int gs_rowptr_from_sorted(const int *sorted_keys, int64_t n, int64_t nrows, int *rowptr,
+                          hipStream_t st);
 // ids of rows longer than gsage_long_row_threshold() -> list[0..*count) (count pre-zeroed)
 int gs_list_long_rows(const int *rowptr, int64_t N, int *list, int64_t cap, int *count,
                       hipStream_t st);

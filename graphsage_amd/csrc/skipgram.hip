@@ -241,7 +241,7 @@ __device__ __forceinline__ void sg_term(const int64_t *__restrict__ tg, const in
 __global__ void __launch_bounds__(256)
 sg_terms_k(const int64_t *__restrict__ tg, const int64_t *__restrict__ ctx,
            const int64_t *__restrict__ neg, int64_t B, int64_t K, int64_t N, int *__restrict__ key,
-           int *__restrict__ val, int *__restrict__ deg) {
+           int *__restrict__ val) {
   const int64_t M = B * 2 * (1 + K);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < M; e += stride) {
@@ -254,7 +254,6 @@ sg_terms_k(const int64_t *__restrict__ tg, const int64_t *__restrict__ ctx,
     int k = bad ? (int)N : (int)dst;          // sentinel row N: sorted last, never read
     key[e] = k;
     val[e] = (int)e;
-    atomicAdd(&deg[k], 1);
   }
 }
 
@@ -280,7 +279,7 @@ sg_materialise_k(const int *__restrict__ perm, const int64_t *__restrict__ tg,
 }
 
 struct DetLayout {
-  size_t total, o_key, o_val, o_kA, o_vA, o_kB, o_vB, o_counts, o_bsum, o_deg, o_rowptr, o_col,
+  size_t total, o_key, o_val, o_kA, o_vA, o_kB, o_vB, o_counts, o_bsum, o_rowptr, o_col,
       o_w, o_long, o_nlong;
   int64_t M, long_cap;
 };
@@ -303,7 +302,6 @@ DetLayout det_layout(int64_t N, int64_t B, int64_t K) {
   L.o_kA = take(m4); L.o_vA = take(m4); L.o_kB = take(m4); L.o_vB = take(m4);
   L.o_counts = take((size_t)ncounts * 4);
   L.o_bsum = take((size_t)((scan_n + GS_SCAN_CH - 1) / GS_SCAN_CH + 1) * 4);
-  L.o_deg = take((size_t)(N + 2) * 4);
   L.o_rowptr = take((size_t)(N + 2) * 4);
   L.o_col = take(m4);
   L.o_w = take(m4);
@@ -403,19 +401,15 @@ extern "C" int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D,
   int *key = (int *)(b + L.o_key), *val = (int *)(b + L.o_val);
   GsSortWs sw{(int *)(b + L.o_kA), (int *)(b + L.o_vA), (int *)(b + L.o_kB), (int *)(b + L.o_vB),
               (int *)(b + L.o_counts), (int *)(b + L.o_bsum)};
-  int *deg = (int *)(b + L.o_deg), *rowptr = (int *)(b + L.o_rowptr);
+  int *rowptr = (int *)(b + L.o_rowptr);
   int *col = (int *)(b + L.o_col);
   float *w = (float *)(b + L.o_w);
   int *longs = (int *)(b + L.o_long), *nlong = (int *)(b + L.o_nlong);
 
-  if (!gs_zero_async(deg, (size_t)(N + 2) * 4, st) ||
-      !gs_zero_async(nlong, 16, st))
-    return GSAGE_ERR_LAUNCH;
+  if (!gs_zero_async(nlong, 16, st)) return GSAGE_ERR_LAUNCH;
   hipLaunchKernelGGL(sg_terms_k, dim3(gs_grid(L.M, 256)), dim3(256), 0, st, targets, contexts,
-                     negatives, B, K, N, key, val, deg);
+                     negatives, B, K, N, key, val);
   GSAGE_CHECK_LAUNCH();
-  int rc = gs_exclusive_scan(deg, N + 1, rowptr, sw.bsum, st);
-  if (rc) return rc;
   int bits = 0;
   while ((1ll << bits) <= N) ++bits;
   int *perm = key;   // the keys are dead after the sort's first pass has read them: reuse
@@ -423,7 +417,10 @@ extern "C" int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D,
   //  pass it would read and write the same array, so that case sorts into vB instead)
   int passes = (bits + 7) / 8;
   if (passes == 1) perm = sw.vB;
-  rc = gs_radix_sort_vals(key, val, L.M, bits, perm, sw, st);
+  const int *skey = nullptr;
+  int rc = gs_radix_sort_vals(key, val, L.M, bits, perm, sw, st, &skey);
+  if (rc) return rc;
+  rc = gs_rowptr_from_sorted(skey, L.M, N, rowptr, st);   // row boundaries off the sorted keys
   if (rc) return rc;
   hipLaunchKernelGGL(sg_materialise_k, dim3(gs_grid(L.M, 256)), dim3(256), 0, st, perm, targets,
                      contexts, negatives, B, K, N, coef, grad_loss, col, w);
