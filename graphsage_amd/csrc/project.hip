@@ -12,6 +12,8 @@
 //     with the weights held in registers).
 // Weight gradients are accumulated per workgroup into partial slabs and summed in slab
 // order by a second kernel: no atomics, bitwise reproducible.
+#include <atomic>
+
 #include "gsage_common.h"
 
 namespace {
@@ -253,18 +255,29 @@ __global__ void __launch_bounds__(256) gemm_rows_k(GemmArgs a) {
   }
 }
 
+// hipFuncSetAttribute is per device: remember it per (kernel instantiation, device), so a process
+// that drives several GPUs raises the dynamic-LDS limit on each of them.  An atomic flag: two host
+// threads may both set the attribute (harmless), none may skip it.
+template <typename K>
+static int allow_dynamic_lds(K kernel, size_t lds, std::atomic<bool> (&done)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GSAGE_ERR_LAUNCH;
+  if (!done[dev].load(std::memory_order_acquire)) {
+    if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return GSAGE_ERR_LAUNCH;
+    done[dev].store(true, std::memory_order_release);
+  }
+  return GSAGE_OK;
+}
+
 template <int WM, int WN, int TM, int TN>
 int launch_gemm(const GemmArgs &a, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int stage = (BM + BN) * G_PITCH, ctile = BM * (BN + 4);
   constexpr size_t lds = sizeof(float) * (stage > ctile ? stage : ctile);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)gemm_rows_k<WM, WN, TM, TN>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return GSAGE_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<bool> done[64];
+  if (int rc = allow_dynamic_lds(gemm_rows_k<WM, WN, TM, TN>, lds, done)) return rc;
   dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Ncols / BN));
   hipLaunchKernelGGL((gemm_rows_k<WM, WN, TM, TN>), grid, dim3(256), lds, st, a);
   GSAGE_CHECK_LAUNCH();
@@ -445,13 +458,8 @@ template <int TN>
 int launch_gemm_wide(const GemmArgs &a, hipStream_t st) {
   constexpr int BN = 128 * TN;
   constexpr size_t lds = sizeof(float) * (1 * (128 + BN) * G_PITCH + 128 * 4);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)gemm_wide_k<TN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return GSAGE_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<bool> done[64];
+  if (int rc = allow_dynamic_lds(gemm_wide_k<TN>, lds, done)) return rc;
   dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.Ncols / BN));
   hipLaunchKernelGGL((gemm_wide_k<TN>), grid, dim3(512), lds, st, a);
   GSAGE_CHECK_LAUNCH();
