@@ -121,11 +121,20 @@ __global__ void __launch_bounds__(256) skipgram_fwd_vec_k(SgArgs a) {
         s += __shfl_xor(s, 1, 64);
         dotv[u] = s;
       }
-      if (sub == 0) {
+      // after the xor-reduction every lane of the group holds all 6 dot products: lane u of the
+      // group finishes term u (sigmoid, softplus, coefficient store) instead of lane 0 doing
+      // six in a row
+      {
+        float myv = dotv[0];
+        bool myok = ok[0];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          int64_t r = r0 + u;
-          if (ok[u]) sg_terms(a, b, (int)r, dotv[u], st);
+        for (int u = 1; u < 6; ++u) {
+          myv = sub == u ? dotv[u] : myv;
+          myok = sub == u ? ok[u] : myok;
+        }
+        const int64_t r = r0 + sub;
+        if (sub < 6) {
+          if (myok) sg_terms(a, b, (int)r, myv, st);
           else if (active && r < R) a.coef[b * R + r] = 0.f;
         }
       }
