@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--cpu-nodes", type=int, default=200_000)
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache-input-aggregation", action="store_true",
+                    help="opt-in extra (not the headline): keep mean_j x_j of the constant input "
+                         "features across steps instead of recomputing it like the reference")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,7 +154,8 @@ def main():
         f"hub rows {graph.n_long.tolist()}, max in-degree {int(graph.in_degree().max())}")
 
     torch.manual_seed(0)
-    model = GraphSAGE(7, hidden, out_dim, 2, args.dropout).to(dev)
+    model = GraphSAGE(7, hidden, out_dim, 2, args.dropout,
+                      cache_input_aggregation=args.cache_input_aggregation).to(dev)
     step = TrainStep(model, x, ei)
     nbatch = 4
     batches = [cooccurrence_batch(ei, nodes, B, K, seed=1000 * (rank + 1) + i) for i in range(nbatch)]
@@ -217,6 +221,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "nodes": nodes, "edges": E, "negatives": K,
                        "pairs_per_gpu": B, "global_batch": B * world, "dropout": args.dropout,
+                       "input_aggregation": "cached across steps (opt-in, not the reference's work)"
+                       if args.cache_input_aggregation else "recomputed every step",
                        "parallelism": f"replicated graph, pair-sharded dp{world}",
                        "loss_backward": "deterministic (sorted)" if ops.loss_bwd_deterministic(nodes, B, K)
                        else "atomic",

@@ -121,6 +121,23 @@ class GraphCache:
         self._store[k] = (weakref.ref(x), x._version, xp)
         return xp
 
+    def aggregated(self, x_key: torch.Tensor, x: torch.Tensor, graph: "GraphCSR", compute):
+        """``compute(graph, x)`` (the mean aggregation of the INPUT features), cached per
+        (feature tensor object + version, graph): node features and graph are constant across
+        training steps, so an opt-in caller (``GraphSAGE(cache_input_aggregation=True)``) can skip
+        the first layer's gather after the first step.  ``x_key`` is the caller's tensor, ``x``
+        the (possibly padded) one that is aggregated."""
+        k = ("agg", id(x_key), id(graph))
+        ent = self._store.get(k)
+        if ent is not None:
+            ref, version, gref, agg = ent
+            if ref() is x_key and version == x_key._version and gref() is graph:
+                return agg
+            del self._store[k]
+        agg = compute(graph, x)
+        self._store[k] = (weakref.ref(x_key), x_key._version, weakref.ref(graph), agg)
+        return agg
+
     def clear(self) -> None:
         self._store.clear()
 

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .graph import GraphCSR, default_cache
-from .ops import SAGELayerFunction
+from .ops import SAGELayerFunction, aggregate_mean
 
 
 _VEC_WIDTHS = (4, 8, 16, 32, 64, 128, 256)
@@ -49,6 +49,8 @@ class SAGEConv(nn.Module):
         self.aggr = aggr
         self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
         self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+        # opt-in: reuse mean_j x_j across calls while x (no grad) and the graph stay the same
+        self.cache_aggregation = False
 
     def reset_parameters(self) -> None:
         self.lin_l.reset_parameters()
@@ -58,6 +60,7 @@ class SAGEConv(nn.Module):
             seed: int = 0, keep_mask: Optional[torch.Tensor] = None,
             force_generic: bool = False) -> torch.Tensor:
         w_l, w_r = self.lin_l.weight, self.lin_r.weight
+        x_key = x
         width = vector_width(x.size(1))
         if width != x.size(1) and not force_generic:
             # e.g. the 7 memory features -> 8 columns: 32-byte rows that the 16-byte-per-lane
@@ -65,8 +68,11 @@ class SAGEConv(nn.Module):
             pad = width - x.size(1)
             x = default_cache().padded(x, width)
             w_l, w_r = F.pad(w_l, (0, pad)), F.pad(w_r, (0, pad))
+        agg = None
+        if self.cache_aggregation and not x_key.requires_grad:
+            agg = default_cache().aggregated(x_key, x, graph, aggregate_mean)
         return SAGELayerFunction.apply(x, w_l, self.lin_l.bias, w_r, graph, epilogue, p, seed,
-                                       keep_mask, force_generic)
+                                       keep_mask, force_generic, agg)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         graph = default_cache().get(edge_index, x.size(0))
@@ -81,7 +87,11 @@ class GraphSAGE(nn.Module):
 
     def __init__(self, in_channels: int = 7, hidden_channels: int = 64, out_channels: int = 64,
                  num_layers: int = 2, dropout: float = 0.3, aggregator: str = "mean",
-                 normalize_output: bool = True):
+                 normalize_output: bool = True, cache_input_aggregation: bool = False):
+        """``cache_input_aggregation`` (not in the reference): keep the first layer's
+        ``mean_j x_j`` between calls while the feature tensor and the graph are unchanged, as
+        they are across training steps.  Same results; off by default because the reference
+        recomputes it, and so does the benchmark."""
         super().__init__()
         self.in_channels = in_channels
         self.hidden_channels = hidden_channels
@@ -100,6 +110,7 @@ class GraphSAGE(nn.Module):
         # inside the K3 epilogue, not by this module
         self.dropout = nn.Dropout(dropout)
         self._force_generic = False
+        self.convs[0].cache_aggregation = bool(cache_input_aggregation)
 
     def _dropout_seed(self) -> int:
         # CPU generator: reproducible under torch.manual_seed, no device sync

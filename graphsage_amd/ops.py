@@ -228,14 +228,14 @@ class SAGELayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_l, b_l, w_r, graph: GraphCSR, epilogue: int, p: float, seed: int,
-                keep_mask, force_generic: bool):
+                keep_mask, force_generic: bool, agg_cached=None):
         x = _f32c(x, "x")
         w_l, b_l, w_r = _f32c(w_l, "lin_l.weight"), _f32c(b_l, "lin_l.bias"), _f32c(w_r, "lin_r.weight")
         if x.dim() != 2 or x.size(0) != graph.num_nodes:
             raise ValueError(f"x must be [num_nodes={graph.num_nodes}, F], got {tuple(x.shape)}")
         if w_l.shape != w_r.shape or w_l.size(1) != x.size(1) or b_l.numel() != w_l.size(0):
             raise ValueError("SAGEConv weight shapes do not match the input width")
-        agg = aggregate_mean(graph, x)
+        agg = agg_cached if agg_cached is not None else aggregate_mean(graph, x)
         out, rnorm = project_fwd(agg, x, w_l, b_l, w_r, epilogue, keep_mask, seed, p, force_generic)
         ctx.graph, ctx.epilogue, ctx.p, ctx.force_generic = graph, epilogue, p, force_generic
         ctx.save_for_backward(x, agg, out, rnorm, w_l, w_r)
@@ -253,7 +253,7 @@ class SAGELayerFunction(torch.autograd.Function):
         if need_x:
             # grad_agg arrives pre-scaled by inv_deg[row]; gather it over the transposed CSR
             grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x)
-        return grad_x, gwl, gb, gwr, None, None, None, None, None, None
+        return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None
 
 
 class SkipGramFunction(torch.autograd.Function):

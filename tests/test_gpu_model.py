@@ -247,3 +247,29 @@ def test_full_size_c4_forward_and_weight_gradients_match_torch_composition():
         tol = (1e-5 if k.startswith("convs.1.") else 1e-3) * float(ref.abs().max())
         worst = float((got[k].double() - ref).abs().max())
         assert worst <= tol, (k, worst, tol)
+
+
+def test_cached_input_aggregation_gives_identical_steps():
+    """GraphSAGE(cache_input_aggregation=True): same embeddings and gradients bit for bit, and
+    the cache follows in-place edits of the features (version counter)."""
+    from graphsage_amd import GraphSAGE
+    from graphsage_amd.synth import memory_features, powerlaw_graph
+    n = 3000
+    ei = powerlaw_graph(n, 10, seed=2, device="cuda")
+    x = memory_features(n, seed=2, device="cuda")
+    torch.manual_seed(0)
+    a = GraphSAGE(7, 64, 64, 2, 0.0).cuda()
+    b = GraphSAGE(7, 64, 64, 2, 0.0, cache_input_aggregation=True).cuda()
+    b.load_state_dict(a.state_dict())
+    for step in range(3):
+        if step == 2:
+            x.mul_(0.5)                                    # in place: the cached mean must go
+        ea, eb = a(x, ei), b(x, ei)
+        assert torch.equal(ea, eb)
+        ea.square().sum().backward()
+        eb.square().sum().backward()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.equal(pa.grad, pb.grad)
+        a.zero_grad(), b.zero_grad()
+    xg = x.clone().requires_grad_()
+    assert torch.equal(a(xg, ei), b(xg, ei))               # features with grad: never cached
