@@ -249,9 +249,12 @@ __device__ __forceinline__ void sg_term(const int64_t *__restrict__ tg, const in
 
 __global__ void __launch_bounds__(256)
 sg_terms_k(const int64_t *__restrict__ tg, const int64_t *__restrict__ ctx,
-           const int64_t *__restrict__ neg, int64_t B, int64_t K, int64_t N, int *__restrict__ key,
-           int *__restrict__ val) {
+           const int64_t *__restrict__ neg, int64_t B, int64_t K, int64_t N,
+           const float *__restrict__ coef, const float *__restrict__ grad_loss,
+           int *__restrict__ key, int *__restrict__ val, int *__restrict__ tsrc,
+           float *__restrict__ tw) {
   const int64_t M = B * 2 * (1 + K);
+  const float g = *grad_loss;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < M; e += stride) {
     int64_t b = e / (2 * (1 + K));
@@ -263,33 +266,27 @@ sg_terms_k(const int64_t *__restrict__ tg, const int64_t *__restrict__ ctx,
     int k = bad ? (int)N : (int)dst;          // sentinel row N: sorted last, never read
     key[e] = k;
     val[e] = (int)e;
+    // source row and weight of the term, in term order: after the sort they are fetched through
+    // the permutation (two 4-byte reads) instead of being re-derived from the pair arrays
+    tsrc[e] = bad ? 0 : (int)src;
+    tw[e] = bad ? 0.f : coef[b * (1 + K) + r] * g;
   }
 }
 
 __global__ void __launch_bounds__(256)
-sg_materialise_k(const int *__restrict__ perm, const int64_t *__restrict__ tg,
-                 const int64_t *__restrict__ ctx, const int64_t *__restrict__ neg, int64_t B,
-                 int64_t K, int64_t N, const float *__restrict__ coef,
-                 const float *__restrict__ grad_loss, int *__restrict__ col, float *__restrict__ w) {
-  const int64_t M = B * 2 * (1 + K);
-  const float g = *grad_loss;
+sg_materialise_k(const int *__restrict__ perm, int64_t M, const int *__restrict__ tsrc,
+                 const float *__restrict__ tw, int *__restrict__ col, float *__restrict__ w) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < M; p += stride) {
-    int64_t e = perm[p];
-    int64_t b = e / (2 * (1 + K));
-    int s = (int)(e % (2 * (1 + K)));
-    int64_t dst, src;
-    int r;
-    sg_term(tg, ctx, neg, K, b, s, dst, src, r);
-    bool bad = (uint64_t)dst >= (uint64_t)N || (uint64_t)src >= (uint64_t)N;
-    col[p] = bad ? 0 : (int)src;
-    w[p] = bad ? 0.f : coef[b * (1 + K) + r] * g;
+    const int e = perm[p];
+    col[p] = tsrc[e];
+    w[p] = tw[e];
   }
 }
 
 struct DetLayout {
   size_t total, o_key, o_val, o_kA, o_vA, o_kB, o_vB, o_counts, o_bsum, o_rowptr, o_col,
-      o_w, o_long, o_nlong;
+      o_w, o_tsrc, o_tw, o_long, o_nlong;
   int64_t M, long_cap;
 };
 
@@ -314,6 +311,8 @@ DetLayout det_layout(int64_t N, int64_t B, int64_t K) {
   L.o_rowptr = take((size_t)(N + 2) * 4);
   L.o_col = take(m4);
   L.o_w = take(m4);
+  L.o_tsrc = take(m4);
+  L.o_tw = take(m4);
   L.o_long = take((size_t)L.long_cap * 4);
   L.o_nlong = take(16);
   L.total = off;
@@ -416,8 +415,10 @@ extern "C" int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D,
   int *longs = (int *)(b + L.o_long), *nlong = (int *)(b + L.o_nlong);
 
   if (!gs_zero_async(nlong, 16, st)) return GSAGE_ERR_LAUNCH;
-  hipLaunchKernelGGL(sg_terms_k, dim3(gs_grid(L.M, 256)), dim3(256), 0, st, targets, contexts,
-                     negatives, B, K, N, key, val);
+  int *tsrc = (int *)(b + L.o_tsrc);
+  float *tw = (float *)(b + L.o_tw);
+  hipLaunchKernelGGL(sg_terms_k, dim3(gs_grid(L.M, 256, 1 << 16)), dim3(256), 0, st, targets,
+                     contexts, negatives, B, K, N, coef, grad_loss, key, val, tsrc, tw);
   GSAGE_CHECK_LAUNCH();
   int bits = 0;
   while ((1ll << bits) <= N) ++bits;
@@ -431,8 +432,8 @@ extern "C" int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D,
   if (rc) return rc;
   rc = gs_rowptr_from_sorted(skey, L.M, N, rowptr, st);   // row boundaries off the sorted keys
   if (rc) return rc;
-  hipLaunchKernelGGL(sg_materialise_k, dim3(gs_grid(L.M, 256)), dim3(256), 0, st, perm, targets,
-                     contexts, negatives, B, K, N, coef, grad_loss, col, w);
+  hipLaunchKernelGGL(sg_materialise_k, dim3(gs_grid(L.M, 256, 1 << 16)), dim3(256), 0, st, perm,
+                     L.M, tsrc, tw, col, w);
   GSAGE_CHECK_LAUNCH();
   rc = gs_list_long_rows(rowptr, N, longs, L.long_cap, nlong, st);
   if (rc) return rc;

@@ -174,7 +174,7 @@ def skipgram_fwd(emb, targets, contexts, negatives, scale, norm_b=None, norm_bk=
 # Loss backward: a float-atomic scatter, or the sort-based form (bitwise reproducible, no
 # zero-fill).  Same values up to summation order.  Which is faster depends on how many of the
 # 2(1+K)B terms land on each of the N rows: at B = 2^20, K = 5 the sorted form wins at 100 k and
-# 1 M nodes (2.5 vs 3.35 and 9.8 vs 10.9 ms per step) and loses at 10 M (31.9 vs 30.1), and for
+# 1 M nodes (2.25 vs 3.35 and 9.6 vs 10.9 ms per step) and loses at 10 M (31.9 vs 30.1), and for
 # small batches its dozen launches cost more than they save.  GSAGE_LOSS_BWD=atomic|det forces
 # one, SkipGramLoss(deterministic=True/False) does the same per module; default "auto".
 LOSS_BWD_MODE = os.environ.get("GSAGE_LOSS_BWD", "auto")

@@ -145,7 +145,9 @@ def test_deterministic_and_atomic_backward_agree_with_oracle(n, d, b, k, hot):
     atom = ops.skipgram_bwd(e, tt, cc, nn_, coef, one, deterministic=False)
     assert torch.equal(det1, det2)                              # bitwise reproducible
     assert_close(det1, emb.grad, rtol=1e-5, floor=2e-6, what="deterministic")
-    assert_close(atom, emb.grad, rtol=1e-5, floor=2e-6, what="atomic")
+    # float atomics add in arrival order: with every pair on one target row that row is a sum of
+    # b*(1+k) terms in a different order each run, so its bar is wider
+    assert_close(atom, emb.grad, rtol=1e-5, floor=2e-5 if hot else 2e-6, what="atomic")
 
 
 def test_deterministic_backward_ignores_out_of_range_pairs():
