@@ -22,7 +22,7 @@ constexpr int RS_TILE = RS_T * RS_ROUNDS;   // 4096 items per block
 static_assert(RS_TILE == GS_RS_TILE, "gsage_sort.h out of sync");
 constexpr int RS_WAVE_ITEMS = 64 * RS_ROUNDS;
 
-constexpr int LONG_ROW_T = 2048;            // rows longer than this take the hub pass
+constexpr int LONG_ROW_T = 512;             // rows longer than this take the hub pass
 
 __device__ __forceinline__ int wave_incl_scan(int v) {
   const int lane = gs_lane();
