@@ -1,0 +1,44 @@
+"""Long runs that would expose rare failures (stale flags, races): many eager steps at C2 size,
+many captured-graph replays at the reference's default size, both loss-backward forms."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from graphsage_amd import GraphSAGE, SkipGramLoss, TrainStep  # noqa: E402
+from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph  # noqa: E402
+
+
+def run(n, B, steps, captured, deterministic):
+    ei = powerlaw_graph(n, 10 if n < 10_000 else 20, seed=1, device="cuda")
+    x = memory_features(n, seed=1, device="cuda")
+    torch.manual_seed(0)
+    m = GraphSAGE(7, 64, 64, 2, 0.3).cuda()
+    ts = TrainStep(m, x, ei, loss_fn=SkipGramLoss(deterministic=deterministic))
+    batches = [cooccurrence_batch(ei, n, B, 5, seed=s) for s in range(8)]
+    if captured:
+        ts.capture_step(B, 5, preserve_state=True)
+    acc = torch.zeros(8, device="cuda")
+    t0 = time.time()
+    for i in range(steps):
+        b = batches[i % 8]
+        acc += ts.step_captured(*b) if captured else ts.step(*b)
+        if i % 2000 == 1999:
+            print(f"  ... {i + 1} steps, {time.time() - t0:.0f}s", flush=True)
+    host = (acc / steps).tolist()
+    ok = host[7] == 0.0 and all(v == v and abs(v) < 1e6 for v in host[:7])
+    print(f"n={n} B={B} steps={steps} captured={captured} det={deterministic}: mean loss {host[0]:.4f} "
+          f"flag {host[7]} -> {'ok' if ok else 'FAILED'}", flush=True)
+    return ok
+
+
+if __name__ == "__main__":
+    good = True
+    good &= run(500, 1024, 20000, True, False)
+    good &= run(500, 1024, 5000, True, True)
+    good &= run(100_000, 1 << 17, 3000, False, None)
+    good &= run(100_000, 1 << 16, 3000, True, None)
+    sys.exit(0 if good else 1)
