@@ -120,13 +120,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-            _all_reduce = dist.all_reduce
-
-            def staged_all_reduce(t, op=dist.ReduceOp.SUM, group=None):   # gloo sees host memory only
-                h = t.cpu()
-                _all_reduce(h, op=op, group=group)
-                t.copy_(h)
-            dist.all_reduce = staged_all_reduce
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device(f"cuda:{local_rank}"))
@@ -163,11 +156,12 @@ def main():
     if rehearse:
         print(f"[bench r{rank}] batches ready", file=sys.stderr, flush=True)
 
-    token = torch.zeros(1, device=dev)
+    coll_dev = torch.device("cpu") if rehearse else dev      # gloo rehearsal: host tensors
+    token = torch.zeros(1, device=coll_dev)
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:                      # barrier = a one-element all-reduce on the device
+        if world > 1:                      # barrier = a one-element all-reduce
             dist.all_reduce(token)
             torch.cuda.synchronize()
         if rehearse:
@@ -190,7 +184,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     loss = float(stats[0].item())

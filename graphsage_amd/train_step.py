@@ -94,11 +94,23 @@ class TrainStep:
         loss.backward()
         self.flat.extra.copy_(stats)
         if self.world > 1:
-            dist.all_reduce(self.flat.buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce_flat()
         if self.gradient_clip > 0:
             torch.nn.utils.clip_grad_norm_([self.flat.flat_param], self.gradient_clip)
         self.optimizer.step()
         return self.flat.extra
+
+    def _all_reduce_flat(self) -> None:
+        """SUM of [gradients | stats] over the ranks: RCCL on the device buffer; a gloo group
+        (CPU rehearsals, several ranks on one GPU) gets the 36 KB buffer staged through host
+        memory, because gloo's own device path was seen to hang with ranks sharing a GPU."""
+        buf = self.flat.buf
+        if buf.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(host)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
 
     # ------------------------------------------------------------- whole step as one HIP graph
     def capture_step(self, batch_size: int, num_negatives: int, warmup: int = 3,

@@ -1,0 +1,52 @@
+"""Two (or more) ranks on ONE GPU over gloo: every rank trains on its shard of the same global
+batch and must end with the parameters a single process gets from the whole batch.  Launched by
+tests/test_gpu_dist.py through torch.distributed.run; rank 0 prints one JSON line."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from graphsage_amd import GraphSAGE, TrainStep, shard_bounds  # noqa: E402
+from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    n, B, K, steps = 5000, 4099, 5, 3                    # 4099: uneven shards
+    ei = powerlaw_graph(n, 12, seed=3, device=dev)
+    x = memory_features(n, seed=3, device=dev)
+    batches = [cooccurrence_batch(ei, n, B, K, seed=10 + s) for s in range(steps)]
+    torch.manual_seed(0)
+    model = GraphSAGE(7, 64, 64, 2, 0.0).to(dev)
+    init = {k: v.clone() for k, v in model.state_dict().items()}
+    ts = TrainStep(model, x, ei)
+    assert ts.world == world
+    lo, hi = shard_bounds(B, rank, world)
+    losses = []
+    for t, c, neg in batches:
+        stats = ts.step(t[lo:hi], c[lo:hi], neg[lo:hi], global_batch=B)
+        losses.append(float(stats[0]))
+    if rank == 0:
+        # single-process run of the same steps on the whole batches (no process group in use)
+        ref_model = GraphSAGE(7, 64, 64, 2, 0.0).to(dev)
+        ref_model.load_state_dict(init)
+        ref = TrainStep(ref_model, x, ei)
+        ref.world = 1                                     # the group exists, this stepper ignores it
+        ref_losses = [float(ref.step(*b)[0]) for b in batches]
+        worst = max(float((a.detach() - b.detach()).abs().max())
+                    for a, b in zip(model.parameters(), ref_model.parameters()))
+        print(json.dumps({"world": world, "losses": losses, "ref_losses": ref_losses,
+                          "max_param_diff": worst}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
