@@ -41,15 +41,16 @@ SHAPES = [(7, 64), (64, 64), (64, 128), (128, 128), (128, 64), (256, 256), (7, 3
           (5, 3), (64, 96), (20, 64), (7, 100), (8, 128), (7, 256), (8, 64)]
 
 
+# force_generic 0 = the kernel the library picks for the shape; 1 = the VALU kernels, tried where
+# 0 would pick something else; 2 = the generic MFMA tiles in place of the 64 -> 64 special case
+CASES = [(fi, fo, 0) for fi, fo in SHAPES] + \
+        [(fi, fo, 1) for fi, fo in [(64, 64), (128, 64), (7, 64)]] + [(64, 64, 2)]
+
+
 @pytest.mark.parametrize("epi", EPIS)
-@pytest.mark.parametrize("fi,fo", SHAPES)
-@pytest.mark.parametrize("force_generic", [0, 1, 2])
+@pytest.mark.parametrize("fi,fo,force_generic", CASES)
 def test_forward_backward(fi, fo, epi, force_generic):
     from graphsage_amd.ops import project_bwd, project_fwd
-    if force_generic == 1 and (fi, fo) not in [(64, 64), (128, 64), (7, 64)]:
-        pytest.skip("VALU path already selected by shape")
-    if force_generic == 2 and (fi, fo) != (64, 64):
-        pytest.skip("only 64 -> 64 has a specialised kernel to bypass")
     n, p = 333, 0.3          # not a multiple of the 64-row tile
     agg, x, wl, bl, wr, keep, gout = _case(n, fi, fo, fi * 1000 + fo)
     leaves = [t.clone().requires_grad_() for t in (agg, x, wl, bl, wr)]
