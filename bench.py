@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--cpu-nodes", type=int, default=200_000)
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--receptive-field", action="store_true",
+                    help="opt-in extra (not the headline): compute only the 2-hop closure of each "
+                         "batch (pays for small batches on large graphs)")
     ap.add_argument("--cache-input-aggregation", action="store_true",
                     help="opt-in extra (not the headline): keep mean_j x_j of the constant input "
                          "features across steps instead of recomputing it like the reference")
@@ -149,7 +152,7 @@ def main():
     torch.manual_seed(0)
     model = GraphSAGE(7, hidden, out_dim, 2, args.dropout,
                       cache_input_aggregation=args.cache_input_aggregation).to(dev)
-    step = TrainStep(model, x, ei)
+    step = TrainStep(model, x, ei, receptive_field=args.receptive_field)
     nbatch = 4
     batches = [cooccurrence_batch(ei, nodes, B, K, seed=1000 * (rank + 1) + i) for i in range(nbatch)]
     torch.cuda.synchronize()
@@ -215,6 +218,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "nodes": nodes, "edges": E, "negatives": K,
                        "pairs_per_gpu": B, "global_batch": B * world, "dropout": args.dropout,
+                       "graph_pass": "2-hop closure of the batch only (opt-in)" if args.receptive_field
+                       else "full graph every step (as the reference)",
                        "input_aggregation": "cached across steps (opt-in, not the reference's work)"
                        if args.cache_input_aggregation else "recomputed every step",
                        "parallelism": f"replicated graph, pair-sharded dp{world}",

@@ -66,9 +66,10 @@ def segment_gather(rowptr, col, x, row_scale=None, edge_weight=None, add_to=None
     """out[i] = add_to[i] + row_scale[i] * sum_p edge_weight[col[p]] * x[col[p]] (K2/K7)."""
     lib = _lib.load()
     x = _f32c(x, "x")
-    N, F = x.shape
+    F = x.size(1)
+    N = rowptr.numel() - 1            # output rows; x may hold more rows than that (row subsets)
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty(N, F, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         ev = _timer.bracket(f"segment_gather_F{F}") if _timer is not None and _timer.enabled else None
         if ev:

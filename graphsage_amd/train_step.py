@@ -60,7 +60,7 @@ class TrainStep:
                  learning_rate: float = 1e-3, weight_decay: float = 0.0,
                  gradient_clip: float = 1.0, scale_factor: float = 5.0,
                  process_group: Optional[dist.ProcessGroup] = None,
-                 loss_fn: Optional[nn.Module] = None):
+                 loss_fn: Optional[nn.Module] = None, receptive_field: bool = False):
         self.model = model
         self.features = features
         self.edge_index = edge_index
@@ -74,6 +74,8 @@ class TrainStep:
                                           weight_decay=weight_decay, capturable=on_gpu,
                                           foreach=False if not on_gpu else None)
         self._graph = None
+        # opt-in (graphsage_amd/receptive.py): compute only the 2-hop closure of the batch
+        self.receptive_field = bool(receptive_field)
         self.distributed = dist.is_available() and dist.is_initialized()
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
@@ -88,7 +90,14 @@ class TrainStep:
             global_batch = targets.numel() * self.world
         self.model.train()
         self.flat.zero_grad()
-        emb = self.model(self.features, self.edge_index)
+        if self.receptive_field:
+            from .graph import default_cache
+            from .receptive import receptive_forward
+            graph = default_cache().get(self.edge_index, self.features.size(0))
+            emb, targets, contexts, negatives = receptive_forward(
+                self.model, self.features, graph, targets, contexts, negatives)
+        else:
+            emb = self.model(self.features, self.edge_index)
         loss, stats = self.loss_fn.forward_stats(emb, targets, contexts, negatives,
                                                  global_batch=global_batch)
         loss.backward()

@@ -172,3 +172,30 @@ def test_captured_step_with_dropout_draws_new_masks_each_replay():
     l1 = ts.step_captured(*b)[0].item()
     l2 = ts.step_captured(*b)[0].item()
     assert l1 != l2 and abs(l1 - l2) < 1.0
+
+
+@pytest.mark.parametrize("n,b,seed", [(20000, 256, 0), (3000, 64, 1), (500, 1024, 2)])
+def test_receptive_field_step_equals_full_graph_step(n, b, seed):
+    """TrainStep(receptive_field=True) computes only the 2-hop closure of the batch (hub rows,
+    isolated nodes and duplicate ids included) and must train exactly like the full-graph step."""
+    from graphsage_amd import GraphSAGE, TrainStep
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    ei = powerlaw_graph(n, 12, seed=seed, device="cuda")
+    x = memory_features(n, seed=seed, device="cuda")
+    torch.manual_seed(seed)
+    ma = GraphSAGE(7, 64, 64, 2, 0.0).cuda()
+    mb = GraphSAGE(7, 64, 64, 2, 0.0).cuda()
+    mb.load_state_dict(ma.state_dict())
+    full, rf = TrainStep(ma, x, ei), TrainStep(mb, x, ei, receptive_field=True)
+    for s in range(4):
+        t, c, neg = cooccurrence_batch(ei, n, b, 5, seed=100 + s)
+        if s == 1:
+            neg[:, 0] = t[0]                               # a row hit by every pair
+        sa = full.step(t, c, neg).clone()
+        sb = rf.step(t, c, neg).clone()
+        assert_close(sb[:7], sa[:7], rtol=1e-5, floor=1e-6, what=f"stats step {s}")
+        assert sb[7].item() == 0
+    for (name, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert_close(pb, pa, rtol=1e-4, floor=2e-5, what=name)
+    with pytest.raises(IndexError):
+        rf.step(t, c.clone().fill_(n), neg)
