@@ -248,6 +248,13 @@ class SAGELayerFunction(torch.autograd.Function):
         graph = ctx.graph
         need_x = ctx.needs_input_grad[0]
         grad_out = _f32c(grad_out, "grad_out")
+        if ctx.needs_input_grad[10]:
+            # the aggregation came from outside and wants its own gradient (row-subset layers,
+            # graphsage_amd/receptive.py): hand back d/d agg unscaled, no transposed gather here
+            grad_agg, grad_x, gwl, gb, gwr = project_bwd(
+                grad_out, out, rnorm, agg, x, w_l, w_r, None, ctx.epilogue, ctx.p, True,
+                ctx.force_generic)
+            return (grad_x if need_x else None), gwl, gb, gwr, None, None, None, None, None, None, grad_agg
         grad_agg, grad_x, gwl, gb, gwr = project_bwd(
             grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p,
             need_x, ctx.force_generic)
@@ -285,3 +292,24 @@ class SkipGramFunction(torch.autograd.Function):
         grad_emb = skipgram_bwd(emb, targets, contexts, negatives, coef, g,
                                 deterministic=ctx.deterministic)
         return grad_emb, None, None, None, None, None, None, None
+
+
+class RowSubsetMean(torch.autograd.Function):
+    """agg[r] = mean of x over the in-neighbours of the r-th row of a row subset, where ``graph``
+    is the compact CSR of those edges (targets r < n_rows, sources index x).  Backward is the
+    transposed gather with the 1/degree of the target row as the weight: deterministic."""
+
+    @staticmethod
+    def forward(ctx, x, graph: GraphCSR, n_rows: int):
+        x = _f32c(x, "x")
+        ctx.graph, ctx.n_src = graph, x.size(0)
+        return segment_gather(graph.rowptr[:n_rows + 1], graph.col, x, row_scale=graph.inv_deg,
+                              long_rows=graph.long_rows, n_long=graph.n_long[0:1])
+
+    @staticmethod
+    def backward(ctx, grad_agg):
+        g = ctx.graph
+        grad_x = segment_gather(g.rowptr_t, g.col_t, _f32c(grad_agg, "grad_agg"),
+                                edge_weight=g.inv_deg, long_rows=g.long_rows_t,
+                                n_long=g.n_long[1:2])
+        return grad_x, None, None

@@ -7,8 +7,8 @@ in-neighbours' input features.  This module computes exactly that closure with t
 
 * layer 1 on the row subset N1 = T u in(T) ("rectangular": the gather reads the global feature
   table, the outputs are compact),
-* layer 2 as an ordinary SAGEConv on the compact graph (nodes N1, edges into T only),
-* the loss on remapped pair indices; autograd runs the usual backward on the compact tensors.
+* layer 2 on the rows T only, over the compact CSR of their in-edges (sources = positions in N1),
+* the loss on pair indices remapped into T; autograd runs the backward on the compact tensors.
 
 Loss and parameter gradients equal the full-graph step's (same terms, other summation order).
 Opt-in (``TrainStep(..., receptive_field=True)``); it pays when 7*B rows and their two hops are a
@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .graph import GraphCSR, build_csr, default_cache
-from .ops import SAGELayerFunction, segment_gather
+from .ops import RowSubsetMean, SAGELayerFunction, segment_gather
 
 
 def _in_edges(graph: GraphCSR, rows: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -49,8 +49,8 @@ def _rect_graph(n_rows: int, inv_deg: torch.Tensor) -> GraphCSR:
 
 def receptive_forward(model, x: torch.Tensor, graph: GraphCSR, targets: torch.Tensor,
                       contexts: torch.Tensor, negatives: torch.Tensor):
-    """-> (embeddings of the compact node set [n1, D], targets', contexts', negatives' remapped
-    into it).  2-layer models only."""
+    """-> (embeddings of the rows T the batch reads [nT, D], targets', contexts', negatives'
+    remapped into T).  2-layer models only."""
     if len(model.convs) != 2:
         raise ValueError("the receptive-field step covers 2-layer models")
     B = targets.numel()
@@ -89,10 +89,14 @@ def receptive_forward(model, x: torch.Tensor, graph: GraphCSR, targets: torch.Te
         epi, seed, p = _lib.EPI_RELU, 0, 0.0
     h1 = SAGELayerFunction.apply(x1, w_l, conv1.lin_l.bias, w_r, _rect_graph(n1, inv_deg1), epi, p,
                                  seed, None, False, agg1)
-    # ---- layer 2: an ordinary layer on the compact graph (nodes N1, edges into T only)
-    rows2 = torch.repeat_interleave(posT, deg2, output_size=int(col2.numel()))
-    g2 = build_csr(torch.stack([col2, rows2]), n1, check=False)
+    # ---- layer 2 on the rows T only: compact CSR (targets = positions in T, sources = positions
+    #      in N1), mean over it with its own backward, projection with the aggregate handed in
+    r_local = torch.repeat_interleave(torch.arange(nT, device=x.device), deg2,
+                                      output_size=int(col2.numel()))
+    g2 = build_csr(torch.stack([col2, r_local]), n1, check=False)
+    agg2 = RowSubsetMean.apply(h1, g2, nT)
+    root2 = h1[posT]
     epi2 = _lib.EPI_L2NORM if model.normalize_output else _lib.EPI_NONE
-    emb = conv2.run(h1, g2, epi2, 0.0, 0, None, False)
-    remap = posT[inv]
-    return emb, remap[:B], remap[B:2 * B], remap[2 * B:].view_as(negatives)
+    emb = SAGELayerFunction.apply(root2, conv2.lin_l.weight, conv2.lin_l.bias, conv2.lin_r.weight,
+                                  _rect_graph(nT, g2.inv_deg[:nT]), epi2, 0.0, 0, None, False, agg2)
+    return emb, inv[:B], inv[B:2 * B], inv[2 * B:].view_as(negatives)
