@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .graph import GraphCSR, build_csr, default_cache
-from .ops import RowSubsetMean, SAGELayerFunction, segment_gather
+from .ops import RowSubsetMean, SAGELayerFunction, aggregate_mean, segment_gather
 
 
 def _in_edges(graph: GraphCSR, rows: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -65,10 +65,6 @@ def receptive_forward(model, x: torch.Tensor, graph: GraphCSR, targets: torch.Te
     n1 = N1.numel()
     # ---- layer 1 on the rows N1, sources read from the global feature table
     conv1, conv2 = model.convs[0], model.convs[1]
-    rp1, col1, deg1 = _in_edges(graph, N1)
-    thr = _lib.load().gsage_long_row_threshold()
-    long1 = torch.nonzero(deg1 > thr).to(torch.int32).view(-1)
-    n_long1 = torch.tensor([long1.numel()], dtype=torch.int32, device=x.device)
     w_l, w_r = conv1.lin_l.weight, conv1.lin_r.weight
     from .graphsage import vector_width
     xg = x
@@ -78,9 +74,17 @@ def receptive_forward(model, x: torch.Tensor, graph: GraphCSR, targets: torch.Te
         pad = width - x.size(1)
         w_l, w_r = torch.nn.functional.pad(w_l, (0, pad)), torch.nn.functional.pad(w_r, (0, pad))
     inv_deg1 = graph.inv_deg[N1]
-    agg1 = segment_gather(rp1, col1, xg, row_scale=inv_deg1,
-                          long_rows=long1 if long1.numel() else None,
-                          n_long=n_long1 if long1.numel() else None)
+    if conv1.cache_aggregation and not x.requires_grad:
+        # the input features' neighbour mean is cached for the whole graph: pick the rows
+        agg1 = default_cache().aggregated(x, xg, graph, aggregate_mean)[N1]
+    else:
+        rp1, col1, deg1 = _in_edges(graph, N1)
+        thr = _lib.load().gsage_long_row_threshold()
+        long1 = torch.nonzero(deg1 > thr).to(torch.int32).view(-1)
+        n_long1 = torch.tensor([long1.numel()], dtype=torch.int32, device=x.device)
+        agg1 = segment_gather(rp1, col1, xg, row_scale=inv_deg1,
+                              long_rows=long1 if long1.numel() else None,
+                              n_long=n_long1 if long1.numel() else None)
     x1 = xg[N1]
     p = float(model.dropout_rate)
     if model.training and p > 0.0:

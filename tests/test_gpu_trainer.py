@@ -184,7 +184,7 @@ def test_receptive_field_step_equals_full_graph_step(n, b, seed):
     x = memory_features(n, seed=seed, device="cuda")
     torch.manual_seed(seed)
     ma = GraphSAGE(7, 64, 64, 2, 0.0).cuda()
-    mb = GraphSAGE(7, 64, 64, 2, 0.0).cuda()
+    mb = GraphSAGE(7, 64, 64, 2, 0.0, cache_input_aggregation=(seed == 1)).cuda()   # both forms
     mb.load_state_dict(ma.state_dict())
     full, rf = TrainStep(ma, x, ei), TrainStep(mb, x, ei, receptive_field=True)
     for s in range(4):
