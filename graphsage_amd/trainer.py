@@ -144,7 +144,8 @@ class GraphSAGETrainer:
             self.val_batch_generator = BatchGenerator(val, negative_sampler, self.batch_size * 2,
                                                       self.num_negatives, self.device)
         self.stepper = TrainStep(model, features, edge_index, self.learning_rate, self.weight_decay,
-                                 self.gradient_clip)
+                                 self.gradient_clip,
+                                 receptive_field=bool(tc.get("receptive_field", False)))
         # full batches replay ONE captured HIP graph when the step is launch-bound (small graphs:
         # the reference's default 500-node graph steps in 0.23 ms instead of 0.63 ms); "auto"
         # keeps the eager step where the per-layer mask tensors of the captured form would be
@@ -152,7 +153,7 @@ class GraphSAGETrainer:
         hg = tc.get("hip_graph", "auto")
         self._use_graph = (hg is True or (hg == "auto" and features.size(0) <= 200_000)) and \
             self.stepper.world == 1 and len(self.batch_generator) > 1 and \
-            self.train_pairs[0].numel() >= self.batch_size
+            self.train_pairs[0].numel() >= self.batch_size and not self.stepper.receptive_field
         self._graph_ready = False
         self.optimizer = self.stepper.optimizer
         self.loss_fn = self.stepper.loss_fn
