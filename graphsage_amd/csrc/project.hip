@@ -674,13 +674,14 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
               const float *__restrict__ x, const float *__restrict__ bp /* [128][64] */,
               const float *__restrict__ agg_scale, int64_t M, float inv_keep,
               float *__restrict__ grad_agg, float *__restrict__ grad_x,
-              float *__restrict__ slabs) {
+              float *__restrict__ slabs, uint32_t *__restrict__ nz_mask) {
   // 32-row tiles, both LDS tiles double-buffered: one barrier per tile, 51 KB per workgroup and
   // <= 168 VGPRs, so three workgroups share a CU and their MFMA phases interleave
   constexpr int TR = 32;
   __shared__ __align__(16) float Ac[2][TR * S64_AP];
   __shared__ __align__(16) float Dp[2][TR * S64_DP];
   __shared__ float sc[2][TR];
+  __shared__ unsigned nzs[2][8];   // per (half-tile, wave): which of its 4 dpre rows are non-zero
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   // dX: wave w owns output columns 32w..32w+31 of [grad_agg | grad_x] for all 32 rows
   float4 breg[8];
@@ -740,11 +741,25 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
       *(float4 *)(Dpb + r * S64_DP + c4) = d;
       *(float4 *)(Acb + r * S64_AP + c4) = av[p];
       *(float4 *)(Acb + r * S64_AP + 64 + c4) = xv[p];
+      if (nz_mask) {
+        // a dpre row of zeros gives rows of zeros in grad_agg and grad_x: one bit per row tells
+        // the transposed gather which rows it need not fetch (a tile of 32 rows = one word)
+        const unsigned long long b = __ballot(d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f);
+        if (lane == 0)
+          nzs[buf][p * 4 + w] = ((b & 0xFFFFull) ? 1u : 0u) | (((b >> 16) & 0xFFFFull) ? 2u : 0u) |
+                                (((b >> 32) & 0xFFFFull) ? 4u : 0u) | ((b >> 48) ? 8u : 0u);
+      }
     }
     if (t < TR) sc[buf][t] = scv;
     // the only barrier of the tile: the other buffer was last read before every wave reached
     // the previous one, so the next tile may be staged into it without a second barrier
     __syncthreads();
+    if (nz_mask && t == 0) {
+      unsigned word = 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) word |= nzs[buf][q] << (q * 4);
+      nz_mask[tile] = word;
+    }
     if (tile + gridDim.x < ntiles) BWD64_FETCH((tile + gridDim.x) * TR)
     // ---- dX (K = 64 dpre columns) and dW (K = the tile's 32 rows), interleaved
     f32x16 a0;
@@ -1309,13 +1324,18 @@ extern "C" size_t gsage_project_bwd_workspace_bytes(int64_t N, int64_t Fi, int64
   return pack + (slabs > slabs16 ? slabs : slabs16);
 }
 
-extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const float *rnorm,
-                                 const float *agg, const float *x, const float *w_l,
-                                 const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
-                                 int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
-                                 float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
-                                 void *ws, size_t ws_bytes, int force_generic,
-                                 gsage_stream_t stream) {
+static __global__ void __launch_bounds__(256) fill_words_k(uint32_t *p, int64_t words, uint32_t v) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) p[i] = v;
+}
+
+extern "C" int gsage_project_bwd_nz(const float *grad_out, const float *out, const float *rnorm,
+                                    const float *agg, const float *x, const float *w_l,
+                                    const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
+                                    int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
+                                    float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
+                                    void *ws, size_t ws_bytes, int force_generic,
+                                    uint32_t *nz_mask, gsage_stream_t stream) {
   if (N < 0 || Fi <= 0 || Fo <= 0 || !grad_out || !agg || !x || !w_l || !w_r || !grad_w_l ||
       !grad_b || !grad_w_r || !ws)
     return GSAGE_ERR_INVALID_ARG;
@@ -1350,13 +1370,21 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
       auto kern = epilogue == GSAGE_EPI_NONE ? bwd64_fused_k<0>
                   : epilogue == GSAGE_EPI_L2NORM ? bwd64_fused_k<2> : bwd64_fused_k<1>;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x,
-                         wp, agg_scale, N, ik, grad_agg, grad_x, slabs);
+                         wp, agg_scale, N, ik, grad_agg, grad_x, slabs, nz_mask);
       GSAGE_CHECK_LAUNCH();
       hipLaunchKernelGGL(reduce_slabs_k, dim3((unsigned)((2 * Fi * Fo + Fo + 63) / 64)), dim3(256), 0,
                          st, slabs, grid, fi, fo, grad_w_l, grad_w_r, grad_b);
       GSAGE_CHECK_LAUNCH();
       return GSAGE_OK;
     }
+  }
+
+  // the other kernels do not look for zero rows: every row is reported as possibly non-zero
+  if (nz_mask) {
+    const int64_t words = (N + 31) / 32;
+    hipLaunchKernelGGL(fill_words_k, dim3(gs_grid(words, 1024)), dim3(256), 0, st, nz_mask, words,
+                       0xFFFFFFFFu);
+    GSAGE_CHECK_LAUNCH();
   }
 
   // 1. dpre
@@ -1427,4 +1455,16 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
                      slabs, nslab, fi, fo, grad_w_l, grad_w_r, grad_b);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
+}
+
+extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const float *rnorm,
+                                 const float *agg, const float *x, const float *w_l,
+                                 const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
+                                 int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
+                                 float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
+                                 void *ws, size_t ws_bytes, int force_generic,
+                                 gsage_stream_t stream) {
+  return gsage_project_bwd_nz(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, N, Fi, Fo, epilogue,
+                              p, dpre, grad_agg, grad_x, grad_w_l, grad_b, grad_w_r, ws, ws_bytes,
+                              force_generic, nullptr, stream);
 }

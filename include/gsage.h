@@ -96,6 +96,19 @@ int gsage_segment_gather(const int32_t *rowptr, const int32_t *col,
                          float *out, const int32_t *long_rows, const int32_t *n_long,
                          gsage_stream_t stream);
 
+/* Same, with a hint: src_nz_mask holds one bit per row of x (bit r%32 of word r/32), and a
+ * CLEAR bit promises that row r of x is all zero, so it is not fetched.  In the training step the
+ * gradient that reaches the layer-2 backward is non-zero only on the rows the pair batch
+ * touched (PyG's backward scatters those zero rows like any other: graphsage.py:138 under
+ * autograd); gsage_project_bwd_nz produces the mask.  NULL => gsage_segment_gather.  The live
+ * neighbours of a row are compacted before they are summed, so sums may differ from the
+ * unmasked call in the last bit (the order is still fixed for a given mask). */
+int gsage_segment_gather_skip(const int32_t *rowptr, const int32_t *col,
+                              const float *row_scale, const float *edge_weight,
+                              const float *x, const float *add_to, int64_t N, int64_t F,
+                              float *out, const int32_t *long_rows, const int32_t *n_long,
+                              const uint32_t *src_nz_mask, gsage_stream_t stream);
+
 /* Weighted variant: out[i,:] = sum_{p in row i} edge_w[p] * x[col[p],:] with one weight per
  * CSR entry (same order as col).  Used by the deterministic loss backward; also the SpMM a
  * weighted graph would need. */
@@ -143,6 +156,16 @@ int gsage_project_bwd(const float *grad_out, const float *out, const float *rnor
                       float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
                       void *ws, size_t ws_bytes, int force_generic,
                       gsage_stream_t stream);
+/* Same, and also writes nz_mask: uint32 [ceil(N/32)], bit r%32 of word r/32 is CLEAR only if
+ * row r of dpre (hence of grad_agg and grad_x) is all zero.  The fused 64 -> 64 kernel tests the
+ * rows as it stages them; every other shape reports all rows as possibly non-zero. */
+int gsage_project_bwd_nz(const float *grad_out, const float *out, const float *rnorm,
+                         const float *agg, const float *x, const float *w_l,
+                         const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
+                         int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
+                         float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
+                         void *ws, size_t ws_bytes, int force_generic, uint32_t *nz_mask,
+                         gsage_stream_t stream);
 
 /* ---------------------------------------------------------- K4 / K5: skip-gram loss
  * K4 replaces SkipGramLoss.forward / forward_with_details (src/model/loss.py:97-136,

@@ -78,6 +78,50 @@ def test_hub_rows_and_isolated_rows(f):
     assert_close(gb.cpu(), x.grad)
 
 
+def _pack_bits(flags: torch.Tensor) -> torch.Tensor:
+    """bool [n] -> int32 words, bit r % 32 of word r // 32."""
+    n = flags.numel()
+    pad = (-n) % 32
+    f = torch.cat([flags.to(torch.int64), torch.zeros(pad, dtype=torch.int64, device=flags.device)])
+    words = (f.view(-1, 32) << torch.arange(32, device=flags.device)).sum(1)
+    return torch.where(words < 2**31, words, words - 2**32).to(torch.int32)
+
+
+@pytest.mark.parametrize("f", [64, 128, 8, 7])
+@pytest.mark.parametrize("density", [0.0, 0.05, 0.5, 1.0])
+def test_zero_row_mask_gives_the_unmasked_result(f, density):
+    """gsage_segment_gather_skip: rows promised to be zero are not fetched; everything else is
+    summed as before (hub rows, isolated rows and weights included).  Only the 64- and 128-wide
+    kernels act on the hint; the others give the same sums by reading everything."""
+    from graphsage_amd import _lib
+    from graphsage_amd.graph import build_csr
+    from graphsage_amd.ops import segment_gather
+    thr = _lib.load().gsage_long_row_threshold()
+    n = 5000
+    gen = torch.Generator().manual_seed(int(density * 100) + f)
+    hub = torch.stack([torch.full((2 * thr + 13,), 7), torch.randint(0, n, (2 * thr + 13,), generator=gen)])
+    ei = torch.cat([hub, torch.randint(0, n - 50, (2, 60000), generator=gen)], dim=1).cuda()
+    g = build_csr(ei, n)
+    assert g.n_long[1].item() >= 1
+    live = torch.rand(n, generator=gen) < density
+    x = (torch.randn(n, f, generator=gen) * live[:, None]).cuda()
+    mask = _pack_bits(live.cuda())
+    base = torch.randn(n, f, generator=gen).cuda()
+    for ew in (None, g.inv_deg):
+        ref = segment_gather(g.rowptr_t, g.col_t, x, edge_weight=ew, add_to=base.clone(),
+                             long_rows=g.long_rows_t, n_long=g.n_long[1:2])
+        got = segment_gather(g.rowptr_t, g.col_t, x, edge_weight=ew, add_to=base.clone(),
+                             long_rows=g.long_rows_t, n_long=g.n_long[1:2], src_nz_mask=mask)
+        assert_close(got, ref)
+        # the promise is taken at its word: garbage in the masked-out rows must not be read
+        xg = x.clone()
+        xg[~live.cuda()] = 1e30
+        got2 = segment_gather(g.rowptr_t, g.col_t, xg, edge_weight=ew, add_to=base.clone(),
+                              long_rows=g.long_rows_t, n_long=g.n_long[1:2], src_nz_mask=mask)
+        if f in (64, 128):
+            assert torch.equal(got2, got)
+
+
 def test_bitwise_reproducible_and_linear_at_c2_size():
     """Full-size properties on the C2 graph: determinism and linearity of the operator."""
     from graphsage_amd.graph import build_csr

@@ -124,3 +124,41 @@ def test_weight_grads_bitwise_reproducible():
     r2 = project_bwd(gout.cuda(), out, rn, d[0], d[1], d[2], d[4], None, _lib.EPI_L2NORM, 0.0, True)
     for a, b in zip(r1, r2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("epi", EPIS)
+@pytest.mark.parametrize("n", [333, 32, 4097])
+def test_backward_zero_row_mask(epi, n):
+    """gsage_project_bwd_nz: a clear bit only where the row of grad_agg / grad_x is all zero, and
+    (for the fused 64 -> 64 kernel) a set bit exactly where the pre-epilogue gradient is not."""
+    from graphsage_amd.ops import project_bwd, project_fwd
+    agg, x, wl, bl, wr, keep, gout = _case(n, 64, 64, n)
+    zero_rows = torch.rand(n, generator=torch.Generator().manual_seed(n)) < 0.6
+    gout[zero_rows] = 0.0
+    d = [t.cuda() for t in (agg, x, wl, bl, wr)]
+    p = 0.3 if epi == _lib.EPI_RELU_DROPOUT else 0.0
+    out, rnorm = project_fwd(*d, epilogue=epi, keep_mask=keep.cuda() if p else None, p=p)
+    ga, gx, gwl, gb, gwr, nz = project_bwd(gout.cuda(), out, rnorm, d[0], d[1], d[2], d[4], None,
+                                           epi, p, True, want_nz_mask=True)
+    assert nz is not None and nz.dtype == torch.int32 and nz.numel() == (n + 31) // 32
+    bits = ((nz.to(torch.int64)[:, None] >> torch.arange(32, device="cuda")) & 1).reshape(-1)
+    assert int(bits[n:].sum()) == 0                      # rows past N are reported as zero
+    bits = bits[:n].bool()
+    nonzero = (ga != 0).any(1) | (gx != 0).any(1)
+    assert not bool((nonzero & ~bits).any())             # never hides a non-zero row
+    assert not bool((bits & zero_rows.cuda()).any())     # and finds every zero gradient row
+    # same numbers as the call without the mask
+    ga0, gx0, gwl0, gb0, gwr0 = project_bwd(gout.cuda(), out, rnorm, d[0], d[1], d[2], d[4], None,
+                                            epi, p, True)
+    for a, b in ((ga, ga0), (gx, gx0), (gwl, gwl0), (gb, gb0), (gwr, gwr0)):
+        assert torch.equal(a, b)
+    # the generic kernels do not look: every row is reported as possibly non-zero
+    nz2 = project_bwd(gout.cuda(), out, rnorm, d[0], d[1], d[2], d[4], None, epi, p, True,
+                      force_generic=2, want_nz_mask=True)[5]
+    assert bool((nz2 == -1).all())
+    # other shapes have no kernel that looks: no mask is handed out
+    a2, x2, wl2, bl2, wr2, _, g2 = _case(n, 128, 64, 1)
+    d2 = [t.cuda() for t in (a2, x2, wl2, bl2, wr2)]
+    o2, r2 = project_fwd(*d2, epilogue=_lib.EPI_NONE)
+    assert project_bwd(g2.cuda(), o2, r2, d2[0], d2[1], d2[2], d2[4], None, _lib.EPI_NONE, 0.0, True,
+                       want_nz_mask=True)[5] is None
