@@ -150,7 +150,7 @@ def test_full_size_c4_conservation_identities():
       transposed sum-gather of ones     ==  out-degree
     and the CSR invariants rowptr[N] == E, rowptr monotone, col within range."""
     from graphsage_amd.graph import build_csr
-    from graphsage_amd.ops import aggregate_mean, aggregate_mean_bwd
+    from graphsage_amd.ops import aggregate_mean, aggregate_mean_bwd, segment_gather
     from graphsage_amd.synth import powerlaw_graph
     n = 10_000_000
     ei = powerlaw_graph(n, 20, seed=42, device="cuda")
@@ -169,3 +169,14 @@ def test_full_size_c4_conservation_identities():
     outdeg = aggregate_mean_bwd(g, ones, prescaled=True)
     assert torch.equal(outdeg[:, 0].to(torch.int64), g.out_degree())
     assert torch.equal(aggregate_mean(g, x), agg)                  # bitwise reproducible
+    # zero-row mask at full size: the same sums as the plain call on the zeroed table, whatever
+    # sits in the rows that are promised to be zero; masked calls are reproducible too
+    live = torch.rand(n, device="cuda") < 0.5
+    mask = _pack_bits(live)
+    xz = x * live[:, None]
+    kw = dict(edge_weight=g.inv_deg, long_rows=g.long_rows_t, n_long=g.n_long[1:2])
+    ref = segment_gather(g.rowptr_t, g.col_t, xz, **kw)
+    xz[~live] = 3e38
+    got = segment_gather(g.rowptr_t, g.col_t, xz, src_nz_mask=mask, **kw)
+    assert_close(got, ref)
+    assert torch.equal(segment_gather(g.rowptr_t, g.col_t, xz, src_nz_mask=mask, **kw), got)
