@@ -285,6 +285,84 @@ int launch_gemm(const GemmArgs &a, hipStream_t st) {
 }
 
 
+// Epilogue of the wide kernels, straight on the accumulators: acc[i][j][r] is row
+// wm*64 + i*32 + (r&3) + 8(r>>2) + 4(lane>>5), column (wn*TN + j)*32 + (lane&31) of the tile
+// (the C layout is the same for the f32 and the bf16 32x32 MFMAs).
+template <int TN>
+__device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][TN], const GemmArgs &a, int64_t row0,
+                                              int n0, int wm, int wn, int lane, float (*rowss)[4]) {
+  constexpr int TM = 2;
+  const EpiArgs &e = a.epi;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);   // global output column
+    if (e.mode != MODE_DX) {
+      const float b = e.bias[n];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + b;
+          if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) v = fmaxf(v, 0.f);
+          if (e.mode == GSAGE_EPI_RELU_DROPOUT) {
+            int64_t grow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (grow < a.M) {
+              uint64_t idx = (uint64_t)grow * (uint64_t)a.Ncols + (uint64_t)n;
+              bool keep = e.keep_mask ? (e.keep_mask[idx] != 0) : dropout_keep(e.seed, idx, e.p);
+              v = keep ? v * e.inv_keep : 0.f;
+            }
+          }
+          acc[i][j][r] = v;
+        }
+    }
+  }
+  if (e.mode == GSAGE_EPI_L2NORM) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) ss += acc[i][j][r] * acc[i][j][r];
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+        ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 16, 64);
+        if ((lane & 31) == 0)
+          rowss[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][wn] = ss;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float ss = rowss[lr][0] + rowss[lr][1] + rowss[lr][2] + rowss[lr][3];
+        float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j][r] *= rn;
+        if (wn == 0 && (lane & 31) == 0 && e.rnorm && row0 + lr < a.M) e.rnorm[row0 + lr] = rn;
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    const bool second = n >= a.N1;                       // uniform over the wave (N1 % 32 == 0)
+    float *C = second ? a.C2 : a.C1;
+    const int ldc = second ? (a.Ncols - a.N1) : a.N1;
+    const int col = second ? n - a.N1 : n;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int64_t grow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (grow < a.M) {
+          float v = acc[i][j][r];
+          if (e.mode == MODE_DX && !second && e.row_scale) v *= e.row_scale[grow];
+          C[grow * ldc + col] = v;
+        }
+      }
+  }
+}
+
 // ---- wide layers (128 / 256 columns): 128-row tiles, 8 waves (2 x 4), each wave 64 rows x
 // 32*TN columns.  Twice the rows per weight-tile fetch of gemm_rows_k (the 256-wide layer was
 // bound by re-reading W from L2 per 64-row tile), and the epilogue works straight on the
@@ -381,77 +459,7 @@ __global__ void __launch_bounds__(512, 4) gemm_wide_k(GemmArgs a) {
 #undef WIDE_GLOAD
 #undef WIDE_SSTORE
 
-  // ---- epilogue on the accumulators: acc[i][j][r] is row wm*64+i*32+(r&3)+8(r>>2)+4(lane>>5),
-  //      column (wn*TN+j)*32 + (lane&31) of the tile
-  const EpiArgs &e = a.epi;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);   // global output column
-    if (e.mode != MODE_DX) {
-      const float b = e.bias[n];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + b;
-          if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) v = fmaxf(v, 0.f);
-          if (e.mode == GSAGE_EPI_RELU_DROPOUT) {
-            int64_t grow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (grow < a.M) {
-              uint64_t idx = (uint64_t)grow * (uint64_t)a.Ncols + (uint64_t)n;
-              bool keep = e.keep_mask ? (e.keep_mask[idx] != 0) : dropout_keep(e.seed, idx, e.p);
-              v = keep ? v * e.inv_keep : 0.f;
-            }
-          }
-          acc[i][j][r] = v;
-        }
-    }
-  }
-  if (e.mode == GSAGE_EPI_L2NORM) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) ss += acc[i][j][r] * acc[i][j][r];
-        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
-        ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 16, 64);
-        if ((lane & 31) == 0)
-          rowss[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][wn] = ss;
-      }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float ss = rowss[lr][0] + rowss[lr][1] + rowss[lr][2] + rowss[lr][3];
-        float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j][r] *= rn;
-        if (wn == 0 && (lane & 31) == 0 && e.rnorm && row0 + lr < a.M) e.rnorm[row0 + lr] = rn;
-      }
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-    const bool second = n >= a.N1;                       // uniform over the wave (N1 % 32 == 0)
-    float *C = second ? a.C2 : a.C1;
-    const int ldc = second ? (a.Ncols - a.N1) : a.N1;
-    const int col = second ? n - a.N1 : n;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int64_t grow = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (grow < a.M) {
-          float v = acc[i][j][r];
-          if (e.mode == MODE_DX && !second && e.row_scale) v *= e.row_scale[grow];
-          C[grow * ldc + col] = v;
-        }
-      }
-  }
+  wide_epilogue<TN>(acc, a, row0, n0, wm, wn, lane, rowss);
 }
 
 template <int TN>
@@ -462,6 +470,198 @@ int launch_gemm_wide(const GemmArgs &a, hipStream_t st) {
   if (int rc = allow_dynamic_lds(gemm_wide_k<TN>, lds, done)) return rc;
   dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.Ncols / BN));
   hipLaunchKernelGGL((gemm_wide_k<TN>), grid, dim3(512), lds, st, a);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}
+
+// ---- the same wide layers on the bf16 matrix pipe at fp32 accuracy.
+// An fp32 number is the exact sum of three bf16 numbers (its mantissa cut into 8+8+8 bits:
+// x1 = top 16 bits of x, x2 = top 16 bits of x - x1, x3 = top 16 bits of x - x1 - x2; the
+// subtractions are exact).  A product a*b is then the sum of nine bf16 products, each exact in
+// the MFMA's fp32 accumulator; the six with the largest weight (a1b1, a1b2, a2b1, a1b3, a2b2,
+// a3b1) are kept, which leaves a relative error of ~2^-23 per product, the size of fp32's own
+// rounding.  Six v_mfma_f32_32x32x16_bf16 (32 cycles for 16 k) do the work of eight
+// v_mfma_f32_32x32x2_f32 (64 cycles for 2 k): 2.7x less matrix-pipe time for the same result
+// to within fp32 rounding.  The weights are split once per call by split_planes_k, the
+// activations as they are staged into LDS.
+//   Tile and wave layout as gemm_wide_k (128 rows x BN columns, 8 waves as 2 x 4, the epilogue
+// on the accumulators).  LDS: per stage three bf16 planes of the A tile and of the B tile,
+// 64-byte rows (32 k), the four 16-byte slots of a row XOR-ed with (row >> 2) & 3 so that both
+// the ds_read_b128 fragment reads (lane = row, 8 consecutive k) and the stores are conflict
+// free without padding; two stages (147 KB for 256 columns), one barrier per 32-k chunk, one
+// workgroup per CU.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+
+// planes[p][e] = p-th bf16 part of bp[e]  (e < total)
+__global__ void split_planes_k(const float *__restrict__ bp, int total, uint16_t *__restrict__ planes) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const float v = bp[e];
+    const uint32_t u1 = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(u1);
+    const uint32_t u2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(u2);
+    planes[e] = (uint16_t)(u1 >> 16);
+    planes[total + e] = (uint16_t)(u2 >> 16);
+    planes[2 * total + e] = (uint16_t)(__float_as_uint(r2) >> 16);
+  }
+}
+
+template <int TN>
+__global__ void __launch_bounds__(512, 2) gemm_wide_split_k(GemmArgs a, const uint16_t *__restrict__ Bpl) {
+  constexpr int BM = 128, BN = 128 * TN, TM = 2;
+  constexpr int NA = BM * 8 / 512;                       // float4 of A per thread per chunk
+  constexpr int PLANE = (BM + BN) * 32;                  // bf16 per plane per stage (A rows, then B rows)
+  constexpr int STAGE = 3 * PLANE;
+  extern __shared__ __align__(16) uint16_t split_smem[]; // 2 stages + rowss
+  float (*rowss)[4] = (float (*)[4])(split_smem + 2 * STAGE);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 2, wn = w & 3;
+  const int64_t row0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int K = a.K, K1 = a.K1, K2 = a.K - a.K1;
+  const int64_t plane_elems = (int64_t)a.Ncols * K;      // one weight plane in global memory
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // A (activations, from HBM) is fetched TWO chunks ahead into alternating register sets, B (the
+  // weight planes, L2-resident) one chunk ahead; B is issued first so that waiting for it leaves
+  // the younger A loads in flight.  No value is touched before its chunk is staged.
+  f32x4v ra0[NA], ra1[NA];
+  u32x4v rb[3][TN];
+#define SPLIT_GLOAD_A(KC, RA)                                                                 \
+  {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                          \
+      const int f = t + i * 512;                                                              \
+      int64_t grow = row0 + (f >> 3);                                                         \
+      const int k = (KC) + (f & 7) * 4;                                                       \
+      grow = grow < a.M ? grow : 0;      /* rows past M: zeroed when split, not here */       \
+      const float *src = (k < K1) ? a.A1 + grow * K1 + k : a.A2 + grow * K2 + (k - K1);       \
+      RA[i] = *(const f32x4v *)src;                                                           \
+    }                                                                                         \
+  }
+#define SPLIT_GLOAD_B(KC)                                                                     \
+  {                                                                                           \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                        \
+        const int f = t + i * 512;           /* 16-byte item: row n = f >> 2, slot = f & 3 */ \
+        rb[pl][i] = *(const u32x4v *)(Bpl + pl * plane_elems + (int64_t)(n0 + (f >> 2)) * K + \
+                                      (KC) + (f & 3) * 8);                                    \
+      }                                                                                       \
+  }
+  // split the staged A values and write all planes of stage ST
+#define SPLIT_SSTORE(ST, RA)                                                                  \
+  {                                                                                           \
+    uint16_t *stg_ = split_smem + (ST) * STAGE;                                               \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                          \
+      const int f = t + i * 512;                                                              \
+      const int row = f >> 3, c4 = f & 7;                                                     \
+      uint32_t p1[4], p2[4], p3[4];                                                           \
+      const bool in = row0 + row < a.M;                                                       \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                         \
+        const float v = in ? RA[i][c] : 0.f;                                                  \
+        p1[c] = __float_as_uint(v) & 0xFFFF0000u;                                             \
+        const float r1 = v - __uint_as_float(p1[c]);                                          \
+        p2[c] = __float_as_uint(r1) & 0xFFFF0000u;                                            \
+        p3[c] = __float_as_uint(r1 - __uint_as_float(p2[c])) & 0xFFFF0000u;                   \
+      }                                                                                       \
+      const int off = row * 32 + (((c4 >> 1) ^ ((row >> 2) & 3)) * 8) + (c4 & 1) * 4;         \
+      *(u32x2v *)(stg_ + off) = (u32x2v){(p1[0] >> 16) | p1[1], (p1[2] >> 16) | p1[3]};       \
+      *(u32x2v *)(stg_ + PLANE + off) =                                                       \
+          (u32x2v){(p2[0] >> 16) | p2[1], (p2[2] >> 16) | p2[3]};                             \
+      *(u32x2v *)(stg_ + 2 * PLANE + off) =                                                   \
+          (u32x2v){(p3[0] >> 16) | p3[1], (p3[2] >> 16) | p3[3]};                             \
+    }                                                                                         \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                        \
+        const int f = t + i * 512;                                                            \
+        const int n = f >> 2, sl = f & 3;                                                     \
+        *(u32x4v *)(stg_ + pl * PLANE + (BM + n) * 32 + ((sl ^ ((n >> 2) & 3)) * 8)) =        \
+            rb[pl][i];                                                                        \
+      }                                                                                       \
+  }
+  // one 32-k chunk out of stage ST: per 16-k step 6 MFMAs per 32x32 tile, smallest terms first
+  // so that they are not rounded away against the big partial sums
+#define SPLIT_COMPUTE(ST)                                                                     \
+  {                                                                                           \
+    const uint16_t *stg = split_smem + (ST) * STAGE;                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                        \
+      const int slot = ks * 2 + (lane >> 5);                                                  \
+      bf16x8 af[TM][3], bf[TN][3];                                                            \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
+        const int row = wm * 64 + i * 32 + (lane & 31);                                       \
+        const int off = row * 32 + ((slot ^ ((row >> 2) & 3)) * 8);                           \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                      \
+          af[i][pl] = *(const bf16x8 *)(stg + pl * PLANE + off);                              \
+      }                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                        \
+        const int n = (wn * TN + j) * 32 + (lane & 31);                                       \
+        const int off = (BM + n) * 32 + ((slot ^ ((n >> 2) & 3)) * 8);                        \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                      \
+          bf[j][pl] = *(const bf16x8 *)(stg + pl * PLANE + off);                              \
+      }                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                      \
+          f32x16 c = acc[i][j];                                                               \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);        \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);        \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);        \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);        \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);        \
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);        \
+          acc[i][j] = c;                                                                      \
+        }                                                                                     \
+    }                                                                                         \
+  }
+
+  // K is a multiple of 64 here (2*Fi or Fo with Fi, Fo in {64, 128, 256}): chunks come in pairs,
+  // the even one staged from ra0 into stage 0, the odd one from ra1 into stage 1
+  SPLIT_GLOAD_A(0, ra0)
+  SPLIT_GLOAD_B(0)
+  SPLIT_GLOAD_A(32, ra1)
+  SPLIT_SSTORE(0, ra0)
+  __syncthreads();
+  for (int kc = 0; kc < K; kc += 64) {
+    // chunk kc (stage 0); stage chunk kc+32 (ra1) into stage 1; fetch A(kc+64) into ra0
+    SPLIT_GLOAD_B(kc + 32)
+    if (kc + 64 < K) SPLIT_GLOAD_A(kc + 64, ra0)
+    SPLIT_COMPUTE(0)
+    SPLIT_SSTORE(1, ra1)
+    __syncthreads();
+    // chunk kc+32 (stage 1); stage chunk kc+64 (ra0) into stage 0; fetch A(kc+96) into ra1
+    const bool more = kc + 64 < K;
+    if (more) SPLIT_GLOAD_B(kc + 64)
+    if (kc + 96 < K) SPLIT_GLOAD_A(kc + 96, ra1)
+    SPLIT_COMPUTE(1)
+    if (more) SPLIT_SSTORE(0, ra0)
+    __syncthreads();
+  }
+#undef SPLIT_GLOAD_A
+#undef SPLIT_GLOAD_B
+#undef SPLIT_SSTORE
+#undef SPLIT_COMPUTE
+  wide_epilogue<TN>(acc, a, row0, n0, wm, wn, lane, rowss);
+}
+
+template <int TN>
+int launch_gemm_wide_split(const GemmArgs &a, uint16_t *planes, hipStream_t st) {
+  constexpr int BN = 128 * TN;
+  constexpr size_t lds = 2 * 3 * (size_t)(128 + BN) * 32 * sizeof(uint16_t) + 128 * 4 * sizeof(float);
+  static std::atomic<bool> done[64];
+  if (int rc = allow_dynamic_lds(gemm_wide_split_k<TN>, lds, done)) return rc;
+  const int total = a.Ncols * a.K;
+  hipLaunchKernelGGL(split_planes_k, dim3(gs_grid(total, 256, 256)), dim3(256), 0, st, a.Bp, total,
+                     planes);
+  GSAGE_CHECK_LAUNCH();
+  dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.Ncols / BN));
+  hipLaunchKernelGGL((gemm_wide_split_k<TN>), grid, dim3(512), lds, st, a, (const uint16_t *)planes);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }
@@ -681,7 +881,6 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
   __shared__ __align__(16) float Ac[2][TR * S64_AP];
   __shared__ __align__(16) float Dp[2][TR * S64_DP];
   __shared__ float sc[2][TR];
-  __shared__ unsigned nzs[2][8];   // per (half-tile, wave): which of its 4 dpre rows are non-zero
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   // dX: wave w owns output columns 32w..32w+31 of [grad_agg | grad_x] for all 32 rows
   float4 breg[8];
@@ -701,7 +900,7 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
 #define BWD64_FETCH(ROW0)                                                          \
   {                                                                                \
     _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                \
-      int64_t row = (ROW0) + p * 16 + rsub;                                        \
+      int64_t row = (ROW0) + rsub * 2 + p;                                         \
       const bool in = row < M;                                                     \
       row = in ? row : 0;                                                          \
       gv[p] = *(const float4 *)(g + row * 64 + c4);                                \
@@ -737,29 +936,15 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
         d.x = yv[p].x > 0.f ? d.x * inv_keep : 0.f; d.y = yv[p].y > 0.f ? d.y * inv_keep : 0.f;
         d.z = yv[p].z > 0.f ? d.z * inv_keep : 0.f; d.w = yv[p].w > 0.f ? d.w * inv_keep : 0.f;
       }
-      const int r = p * 16 + rsub;
+      const int r = rsub * 2 + p;   // wave w stages rows 8w .. 8w+7 of the tile
       *(float4 *)(Dpb + r * S64_DP + c4) = d;
       *(float4 *)(Acb + r * S64_AP + c4) = av[p];
       *(float4 *)(Acb + r * S64_AP + 64 + c4) = xv[p];
-      if (nz_mask) {
-        // a dpre row of zeros gives rows of zeros in grad_agg and grad_x: one bit per row tells
-        // the transposed gather which rows it need not fetch (a tile of 32 rows = one word)
-        const unsigned long long b = __ballot(d.x != 0.f || d.y != 0.f || d.z != 0.f || d.w != 0.f);
-        if (lane == 0)
-          nzs[buf][p * 4 + w] = ((b & 0xFFFFull) ? 1u : 0u) | (((b >> 16) & 0xFFFFull) ? 2u : 0u) |
-                                (((b >> 32) & 0xFFFFull) ? 4u : 0u) | ((b >> 48) ? 8u : 0u);
-      }
     }
     if (t < TR) sc[buf][t] = scv;
     // the only barrier of the tile: the other buffer was last read before every wave reached
     // the previous one, so the next tile may be staged into it without a second barrier
     __syncthreads();
-    if (nz_mask && t == 0) {
-      unsigned word = 0u;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) word |= nzs[buf][q] << (q * 4);
-      nz_mask[tile] = word;
-    }
     if (tile + gridDim.x < ntiles) BWD64_FETCH((tile + gridDim.x) * TR)
     // ---- dX (K = 64 dpre columns) and dW (K = the tile's 32 rows), interleaved
     f32x16 a0;
@@ -783,8 +968,18 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
       }
     }
     if (t < 64) {
+      // wave 0 walks the dpre tile for the bias gradient anyway: lane = column, so one ballot per
+      // row says whether the row is all zero.  A dpre row of zeros gives rows of zeros in grad_agg
+      // and grad_x; one bit per row (a tile of 32 rows = one word) tells the transposed gather
+      // which rows it need not fetch.
+      unsigned word = 0u;
 #pragma unroll 8
-      for (int k = 0; k < TR; ++k) bsum += Dpb[k * S64_DP + t];
+      for (int k = 0; k < TR; ++k) {
+        const float v = Dpb[k * S64_DP + t];
+        bsum += v;
+        word |= (__ballot(v != 0.f) != 0ull ? 1u : 0u) << k;
+      }
+      if (nz_mask && t == 0) nz_mask[tile] = word;
     }
     // ---- dX stores straight from the accumulators (128-byte row segments)
     {
@@ -1251,9 +1446,40 @@ int num_slabs(int64_t N) {
 
 }  // namespace
 
+// weight pack: the fp32 [Ncols][K] matrix, then its three bf16 planes for the split kernels
+static size_t pack_f32_bytes(int64_t Fi, int64_t Fo) {
+  return gs_align_up((size_t)(2 * Fi * Fo) * sizeof(float), 256);
+}
+static size_t pack_bytes(int64_t Fi, int64_t Fo) {
+  return pack_f32_bytes(Fi, Fo) + gs_align_up((size_t)(3 * 2 * Fi * Fo) * sizeof(uint16_t), 256);
+}
+// GSAGE_WIDE_GEMM=f32 keeps the 128/256-wide layers on the fp32 MFMA kernels, =split puts all of
+// them on the bf16-split kernels (A/B measurements, tests); unset: chosen by shape
+static int wide_gemm_mode() {
+  static const int v = [] {
+    const char *e = getenv("GSAGE_WIDE_GEMM");
+    if (!e) return -1;
+    return e[0] == 'f' ? 0 : e[0] == 's' ? 1 : -1;
+  }();
+  return v;
+}
+static int launch_wide(int ncols, const GemmArgs &a, void *pack_base, int64_t Fi, int64_t Fo,
+                       hipStream_t st) {
+  uint16_t *planes = (uint16_t *)((char *)pack_base + pack_f32_bytes(Fi, Fo));
+  // the split kernel runs one workgroup per CU (147 KB of LDS), so its prologue, epilogue and
+  // barriers are not hidden by a second workgroup: it wins where the K loop is long and the tile
+  // wide (256 -> 256 at 10 M rows: 16.0 vs 22.8 ms, with the L2 norm 18.7 vs 24.1 ms) and loses
+  // on short loops (128-wide with the L2-norm epilogue: 8.3 vs 7.9 ms)
+  const int split = wide_gemm_mode();
+  if (split == 0 || (split < 0 && (ncols < 256 || a.K < 256)))
+    return ncols == 128 ? launch_gemm_wide<1>(a, st) : launch_gemm_wide<2>(a, st);
+  return ncols == 128 ? launch_gemm_wide_split<1>(a, planes, st)
+                      : launch_gemm_wide_split<2>(a, planes, st);
+}
+
 extern "C" size_t gsage_project_workspace_bytes(int64_t Fi, int64_t Fo) {
   if (Fi <= 0 || Fo <= 0) return 0;
-  return gs_align_up((size_t)(2 * Fi * Fo) * sizeof(float), 256);
+  return pack_bytes(Fi, Fo);
 }
 
 extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *w_l,
@@ -1295,8 +1521,7 @@ extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *
     GemmArgs a{};
     a.A1 = agg; a.A2 = x; a.Bp = wp; a.C1 = out; a.C2 = nullptr;
     a.M = N; a.K1 = fi; a.K = 2 * fi; a.N1 = fo; a.Ncols = fo; a.epi = e;
-    if (force_generic == 0 && fo == 128) return launch_gemm_wide<1>(a, st);
-    if (force_generic == 0 && fo == 256) return launch_gemm_wide<2>(a, st);
+    if (force_generic == 0 && (fo == 128 || fo == 256)) return launch_wide(fo, a, wpack, Fi, Fo, st);
     return launch_gemm_bn(fo, a, st);
   }
   hipLaunchKernelGGL(pack_t_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
@@ -1318,7 +1543,7 @@ extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *
 
 extern "C" size_t gsage_project_bwd_workspace_bytes(int64_t N, int64_t Fi, int64_t Fo) {
   if (N < 0 || Fi <= 0 || Fo <= 0) return 0;
-  size_t pack = gs_align_up((size_t)(2 * Fi * Fo) * sizeof(float), 256);
+  size_t pack = pack_bytes(Fi, Fo);
   size_t slabs = gs_align_up((size_t)num_slabs(N) * (size_t)(2 * Fi * Fo + Fo) * sizeof(float), 256);
   size_t slabs16 = (Fo % 64 == 0 && Fi <= 8) ? (size_t)DW16_BLOCKS * DW16_SLAB * sizeof(float) : 0;
   return pack + (slabs > slabs16 ? slabs : slabs16);
@@ -1347,7 +1572,7 @@ extern "C" int gsage_project_bwd_nz(const float *grad_out, const float *out, con
   hipStream_t st = gs_stream(stream);
   const int fi = (int)Fi, fo = (int)Fo;
   float *wp = (float *)ws;
-  float *slabs = (float *)((char *)ws + gs_align_up((size_t)(2 * Fi * Fo) * sizeof(float), 256));
+  float *slabs = (float *)((char *)ws + pack_bytes(Fi, Fo));
   const int nslab = num_slabs(N);
 
   if (N == 0) {
@@ -1416,7 +1641,7 @@ extern "C" int gsage_project_bwd_nz(const float *grad_out, const float *out, con
       a.epi.mode = MODE_DX;
       a.epi.row_scale = agg_scale;
       int rc = force_generic != 0 ? launch_gemm_bn(fi, a, st)
-               : (2 * fi == 128 ? launch_gemm_wide<1>(a, st) : launch_gemm_wide<2>(a, st));
+                                  : launch_wide(2 * fi, a, ws, Fi, Fo, st);
       if (rc) return rc;
     } else {
       hipLaunchKernelGGL(dx_generic_k, dim3(gs_grid(N, 4, 256 * 16)), dim3(256), 0, st, dp, w_l,

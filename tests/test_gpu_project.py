@@ -162,3 +162,23 @@ def test_backward_zero_row_mask(epi, n):
     o2, r2 = project_fwd(*d2, epilogue=_lib.EPI_NONE)
     assert project_bwd(g2.cuda(), o2, r2, d2[0], d2[1], d2[2], d2[4], None, _lib.EPI_NONE, 0.0, True,
                        want_nz_mask=True)[5] is None
+
+
+def test_wide_shapes_on_both_kernel_families():
+    """The 128/256-wide layers have two kernel families (fp32 MFMA, and bf16 MFMA on the three-way
+    split of every fp32 operand) chosen by shape; GSAGE_WIDE_GEMM forces one.  The library reads
+    it once, so each family runs this file's forward/backward cases in a child process."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GSAGE_WIDE_GEMM"):
+        pytest.skip("already inside the forced run")
+    here = os.path.dirname(os.path.abspath(__file__))
+    for mode in ("split", "f32"):
+        env = dict(os.environ, GSAGE_WIDE_GEMM=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                            os.path.join(here, "test_gpu_project.py"), "-k",
+                            "test_forward_backward and (128 or 256)"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, f"GSAGE_WIDE_GEMM={mode}:\n{r.stdout[-3000:]}\n{r.stderr[-1000:]}"
+        assert " passed" in r.stdout
