@@ -288,7 +288,7 @@ int launch_gemm(const GemmArgs &a, hipStream_t st) {
 // Epilogue of the wide kernels, straight on the accumulators: acc[i][j][r] is row
 // wm*64 + i*32 + (r&3) + 8(r>>2) + 4(lane>>5), column (wn*TN + j)*32 + (lane&31) of the tile
 // (the C layout is the same for the f32 and the bf16 32x32 MFMAs).
-template <int TN>
+template <int TN, int NWN>   // NWN = column waves of the workgroup (they share the row norms)
 __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][TN], const GemmArgs &a, int64_t row0,
                                               int n0, int wm, int wn, int lane, float (*rowss)[4]) {
   constexpr int TM = 2;
@@ -335,7 +335,9 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][TN], const GemmAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float ss = rowss[lr][0] + rowss[lr][1] + rowss[lr][2] + rowss[lr][3];
+        float ss = rowss[lr][0];
+#pragma unroll
+        for (int q = 1; q < NWN; ++q) ss += rowss[lr][q];
         float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j][r] *= rn;
@@ -459,7 +461,7 @@ __global__ void __launch_bounds__(512, 4) gemm_wide_k(GemmArgs a) {
 #undef WIDE_GLOAD
 #undef WIDE_SSTORE
 
-  wide_epilogue<TN>(acc, a, row0, n0, wm, wn, lane, rowss);
+  wide_epilogue<TN, 4>(acc, a, row0, n0, wm, wn, lane, rowss);
 }
 
 template <int TN>
@@ -484,12 +486,9 @@ int launch_gemm_wide(const GemmArgs &a, hipStream_t st) {
 // v_mfma_f32_32x32x2_f32 (64 cycles for 2 k): 2.7x less matrix-pipe time for the same result
 // to within fp32 rounding.  The weights are split once per call by split_planes_k, the
 // activations as they are staged into LDS.
-//   Tile and wave layout as gemm_wide_k (128 rows x BN columns, 8 waves as 2 x 4, the epilogue
-// on the accumulators).  LDS: per stage three bf16 planes of the A tile and of the B tile,
-// 64-byte rows (32 k), the four 16-byte slots of a row XOR-ed with (row >> 2) & 3 so that both
-// the ds_read_b128 fragment reads (lane = row, 8 consecutive k) and the stores are conflict
-// free without padding; two stages (147 KB for 256 columns), one barrier per 32-k chunk, one
-// workgroup per CU.
+//   LDS holds three bf16 planes of the A tile and of the B tile in unpadded 64-byte rows (32 k),
+// the four 16-byte slots of a row XOR-ed with (row >> 2) & 3, so that the ds_read_b128 fragment
+// reads (lane = row, 8 consecutive k) and the stores are conflict free (SQ_LDS_BANK_CONFLICT 0).
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
@@ -508,20 +507,27 @@ __global__ void split_planes_k(const float *__restrict__ bp, int total, uint16_t
   }
 }
 
-template <int TN>
-__global__ void __launch_bounds__(512, 2) gemm_wide_split_k(GemmArgs a, const uint16_t *__restrict__ Bpl) {
-  constexpr int BM = 128, BN = 128 * TN, TM = 2;
-  constexpr int NA = BM * 8 / 512;                       // float4 of A per thread per chunk
-  constexpr int PLANE = (BM + BN) * 32;                  // bf16 per plane per stage (A rows, then B rows)
-  constexpr int STAGE = 3 * PLANE;
-  extern __shared__ __align__(16) uint16_t split_smem[]; // 2 stages + rowss
-  float (*rowss)[4] = (float (*)[4])(split_smem + 2 * STAGE);
+// ---- 256-column tiles of the split scheme, built for TWO workgroups per CU: 4 waves as 2 x 2,
+// each wave 64 rows x 128 columns (128 accumulator registers; 18 fragment reads per 48 MFMAs),
+// one LDS stage of 74 KB.  The weight planes go global -> LDS directly (global_load_lds_dwordx4:
+// no staging registers; one wave instruction writes 16 rows of 64 bytes, the slot swizzle is
+// applied to the SOURCE address), the activations are fetched into registers under the MFMAs,
+// split before the barrier and written after it.  Two barriers per 32-k chunk; the second
+// workgroup of the CU computes while this one stages.  (Measured and dropped: 16-k steps with the
+// two halves of the stage double-buffered and the DMA issued a step ahead -- one barrier per 48
+// MFMAs instead of two per 96 -- 17.1 ms against 14.7 ms per 256 -> 256 layer at 10 M rows.)
+__global__ void __launch_bounds__(256, 2) gemm_split256_k(GemmArgs a, const uint16_t *__restrict__ Bpl) {
+  constexpr int BM = 128, BN = 256, TM = 2, TN = 4;
+  constexpr int NA = BM * 8 / 256;                       // float4 of A per thread per chunk
+  constexpr int PLANE = (BM + BN) * 32;                  // bf16 per plane (A rows, then B rows)
+  extern __shared__ __align__(16) uint16_t s256_smem[];  // 3 planes + rowss
+  float (*rowss)[4] = (float (*)[4])(s256_smem + 3 * PLANE);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wm = w >> 2, wn = w & 3;
+  const int wm = w >> 1, wn = w & 1;
   const int64_t row0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int K = a.K, K1 = a.K1, K2 = a.K - a.K1;
-  const int64_t plane_elems = (int64_t)a.Ncols * K;      // one weight plane in global memory
+  const int64_t plane_elems = (int64_t)a.Ncols * K;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -531,137 +537,128 @@ __global__ void __launch_bounds__(512, 2) gemm_wide_split_k(GemmArgs a, const ui
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // A (activations, from HBM) is fetched TWO chunks ahead into alternating register sets, B (the
-  // weight planes, L2-resident) one chunk ahead; B is issued first so that waiting for it leaves
-  // the younger A loads in flight.  No value is touched before its chunk is staged.
-  f32x4v ra0[NA], ra1[NA];
-  u32x4v rb[3][TN];
-#define SPLIT_GLOAD_A(KC, RA)                                                                 \
+  f32x4v ra[NA];
+  u32x2v pk[NA][3];
+#define S256_GLOAD_A(KC)                                                                      \
   {                                                                                           \
     _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                          \
-      const int f = t + i * 512;                                                              \
+      const int f = t + i * 256;                                                              \
       int64_t grow = row0 + (f >> 3);                                                         \
       const int k = (KC) + (f & 7) * 4;                                                       \
       grow = grow < a.M ? grow : 0;      /* rows past M: zeroed when split, not here */       \
       const float *src = (k < K1) ? a.A1 + grow * K1 + k : a.A2 + grow * K2 + (k - K1);       \
-      RA[i] = *(const f32x4v *)src;                                                           \
+      ra[i] = *(const f32x4v *)src;                                                           \
     }                                                                                         \
   }
-#define SPLIT_GLOAD_B(KC)                                                                     \
+#define S256_SPLIT_A()                                                                        \
   {                                                                                           \
-    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
-      _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                        \
-        const int f = t + i * 512;           /* 16-byte item: row n = f >> 2, slot = f & 3 */ \
-        rb[pl][i] = *(const u32x4v *)(Bpl + pl * plane_elems + (int64_t)(n0 + (f >> 2)) * K + \
-                                      (KC) + (f & 3) * 8);                                    \
-      }                                                                                       \
-  }
-  // split the staged A values and write all planes of stage ST
-#define SPLIT_SSTORE(ST, RA)                                                                  \
-  {                                                                                           \
-    uint16_t *stg_ = split_smem + (ST) * STAGE;                                               \
     _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                          \
-      const int f = t + i * 512;                                                              \
-      const int row = f >> 3, c4 = f & 7;                                                     \
+      const bool in = row0 + ((t + i * 256) >> 3) < a.M;                                      \
       uint32_t p1[4], p2[4], p3[4];                                                           \
-      const bool in = row0 + row < a.M;                                                       \
       _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                         \
-        const float v = in ? RA[i][c] : 0.f;                                                  \
+        const float v = in ? ra[i][c] : 0.f;                                                  \
         p1[c] = __float_as_uint(v) & 0xFFFF0000u;                                             \
         const float r1 = v - __uint_as_float(p1[c]);                                          \
         p2[c] = __float_as_uint(r1) & 0xFFFF0000u;                                            \
         p3[c] = __float_as_uint(r1 - __uint_as_float(p2[c])) & 0xFFFF0000u;                   \
       }                                                                                       \
-      const int off = row * 32 + (((c4 >> 1) ^ ((row >> 2) & 3)) * 8) + (c4 & 1) * 4;         \
-      *(u32x2v *)(stg_ + off) = (u32x2v){(p1[0] >> 16) | p1[1], (p1[2] >> 16) | p1[3]};       \
-      *(u32x2v *)(stg_ + PLANE + off) =                                                       \
-          (u32x2v){(p2[0] >> 16) | p2[1], (p2[2] >> 16) | p2[3]};                             \
-      *(u32x2v *)(stg_ + 2 * PLANE + off) =                                                   \
-          (u32x2v){(p3[0] >> 16) | p3[1], (p3[2] >> 16) | p3[3]};                             \
+      pk[i][0] = (u32x2v){(p1[0] >> 16) | p1[1], (p1[2] >> 16) | p1[3]};                      \
+      pk[i][1] = (u32x2v){(p2[0] >> 16) | p2[1], (p2[2] >> 16) | p2[3]};                      \
+      pk[i][2] = (u32x2v){(p3[0] >> 16) | p3[1], (p3[2] >> 16) | p3[3]};                      \
     }                                                                                         \
-    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
-      _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                        \
-        const int f = t + i * 512;                                                            \
-        const int n = f >> 2, sl = f & 3;                                                     \
-        *(u32x4v *)(stg_ + pl * PLANE + (BM + n) * 32 + ((sl ^ ((n >> 2) & 3)) * 8)) =        \
-            rb[pl][i];                                                                        \
-      }                                                                                       \
   }
-  // one 32-k chunk out of stage ST: per 16-k step 6 MFMAs per 32x32 tile, smallest terms first
-  // so that they are not rounded away against the big partial sums
-#define SPLIT_COMPUTE(ST)                                                                     \
+#define S256_STORE_A()                                                                        \
   {                                                                                           \
-    const uint16_t *stg = split_smem + (ST) * STAGE;                                          \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                        \
-      const int slot = ks * 2 + (lane >> 5);                                                  \
-      bf16x8 af[TM][3], bf[TN][3];                                                            \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
-        const int row = wm * 64 + i * 32 + (lane & 31);                                       \
-        const int off = row * 32 + ((slot ^ ((row >> 2) & 3)) * 8);                           \
-        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                      \
-          af[i][pl] = *(const bf16x8 *)(stg + pl * PLANE + off);                              \
-      }                                                                                       \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                        \
-        const int n = (wn * TN + j) * 32 + (lane & 31);                                       \
-        const int off = (BM + n) * 32 + ((slot ^ ((n >> 2) & 3)) * 8);                        \
-        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                      \
-          bf[j][pl] = *(const bf16x8 *)(stg + pl * PLANE + off);                              \
-      }                                                                                       \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                      \
-          f32x16 c = acc[i][j];                                                               \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);        \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);        \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);        \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);        \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);        \
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);        \
-          acc[i][j] = c;                                                                      \
-        }                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                          \
+      const int f = t + i * 256;                                                              \
+      const int row = f >> 3, c4 = f & 7;                                                     \
+      const int off = row * 32 + (((c4 >> 1) ^ ((row >> 2) & 3)) * 8) + (c4 & 1) * 4;         \
+      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                        \
+        *(u32x2v *)(s256_smem + pl * PLANE + off) = pk[i][pl];                                \
     }                                                                                         \
+  }
+  // lane l of a wave instruction lands at LDS base + 16 l bytes = row (l >> 2), physical slot
+  // (l & 3) of a 16-row block: it fetches the logical slot that belongs there
+#define S256_GLDS_B(KC)                                                                       \
+  {                                                                                           \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                         \
+        const int blk = q * 4 + w;                                                            \
+        const int n = blk * 16 + (lane >> 2);                                                 \
+        const int sl = (lane & 3) ^ ((n >> 2) & 3);                                           \
+        const uint16_t *src = Bpl + pl * plane_elems + (int64_t)(n0 + n) * K + (KC) + sl * 8; \
+        uint16_t *dst = s256_smem + pl * PLANE + (BM + blk * 16) * 32;                        \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, \
+                                         (__attribute__((address_space(3))) void *)dst, 16,   \
+                                         0, 0);                                               \
+      }                                                                                       \
   }
 
-  // K is a multiple of 64 here (2*Fi or Fo with Fi, Fo in {64, 128, 256}): chunks come in pairs,
-  // the even one staged from ra0 into stage 0, the odd one from ra1 into stage 1
-  SPLIT_GLOAD_A(0, ra0)
-  SPLIT_GLOAD_B(0)
-  SPLIT_GLOAD_A(32, ra1)
-  SPLIT_SSTORE(0, ra0)
+  S256_GLOAD_A(0)
+  S256_GLDS_B(0)
+  S256_SPLIT_A()
+  S256_STORE_A()
   __syncthreads();
-  for (int kc = 0; kc < K; kc += 64) {
-    // chunk kc (stage 0); stage chunk kc+32 (ra1) into stage 1; fetch A(kc+64) into ra0
-    SPLIT_GLOAD_B(kc + 32)
-    if (kc + 64 < K) SPLIT_GLOAD_A(kc + 64, ra0)
-    SPLIT_COMPUTE(0)
-    SPLIT_SSTORE(1, ra1)
-    __syncthreads();
-    // chunk kc+32 (stage 1); stage chunk kc+64 (ra0) into stage 0; fetch A(kc+96) into ra1
-    const bool more = kc + 64 < K;
-    if (more) SPLIT_GLOAD_B(kc + 64)
-    if (kc + 96 < K) SPLIT_GLOAD_A(kc + 96, ra1)
-    SPLIT_COMPUTE(1)
-    if (more) SPLIT_SSTORE(0, ra0)
-    __syncthreads();
+  for (int kc = 0; kc < K; kc += 32) {
+    const bool more = kc + 32 < K;
+    if (more) S256_GLOAD_A(kc + 32)
+#pragma unroll 1
+    for (int ks = 0; ks < 2; ++ks) {
+      const int slot = ks * 2 + (lane >> 5);
+      bf16x8 af[TM][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * 64 + i * 32 + (lane & 31);
+        const int off = row * 32 + ((slot ^ ((row >> 2) & 3)) * 8);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[i][pl] = *(const bf16x8 *)(s256_smem + pl * PLANE + off);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = (wn * TN + j) * 32 + (lane & 31);
+        const int off = (BM + n) * 32 + ((slot ^ ((n >> 2) & 3)) * 8);
+        bf16x8 bf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[pl] = *(const bf16x8 *)(s256_smem + pl * PLANE + off);
+        // smallest terms first, so that they are not rounded away against the big partial sums
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      }
+    }
+    if (more) S256_SPLIT_A()      // waits for the A loads issued before the MFMAs
+    __syncthreads();              // every wave has read the stage
+    if (more) {
+      S256_GLDS_B(kc + 32)
+      S256_STORE_A()
+    }
+    __syncthreads();              // drains the LDS-DMA (vmcnt) and the ds_writes
   }
-#undef SPLIT_GLOAD_A
-#undef SPLIT_GLOAD_B
-#undef SPLIT_SSTORE
-#undef SPLIT_COMPUTE
-  wide_epilogue<TN>(acc, a, row0, n0, wm, wn, lane, rowss);
+#undef S256_GLOAD_A
+#undef S256_SPLIT_A
+#undef S256_STORE_A
+#undef S256_GLDS_B
+  wide_epilogue<TN, 2>(acc, a, row0, n0, wm, wn, lane, rowss);
 }
 
-template <int TN>
-int launch_gemm_wide_split(const GemmArgs &a, uint16_t *planes, hipStream_t st) {
-  constexpr int BN = 128 * TN;
-  constexpr size_t lds = 2 * 3 * (size_t)(128 + BN) * 32 * sizeof(uint16_t) + 128 * 4 * sizeof(float);
+int launch_gemm_split256(const GemmArgs &a, uint16_t *planes, hipStream_t st) {
+  constexpr size_t lds = 3 * (size_t)(128 + 256) * 32 * sizeof(uint16_t) + 128 * 4 * sizeof(float);
   static std::atomic<bool> done[64];
-  if (int rc = allow_dynamic_lds(gemm_wide_split_k<TN>, lds, done)) return rc;
+  if (int rc = allow_dynamic_lds(gemm_split256_k, lds, done)) return rc;
   const int total = a.Ncols * a.K;
   hipLaunchKernelGGL(split_planes_k, dim3(gs_grid(total, 256, 256)), dim3(256), 0, st, a.Bp, total,
                      planes);
   GSAGE_CHECK_LAUNCH();
-  dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.Ncols / BN));
-  hipLaunchKernelGGL((gemm_wide_split_k<TN>), grid, dim3(512), lds, st, a, (const uint16_t *)planes);
+  dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.Ncols / 256));
+  hipLaunchKernelGGL(gemm_split256_k, grid, dim3(256), lds, st, a, (const uint16_t *)planes);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }
@@ -1453,8 +1450,8 @@ static size_t pack_f32_bytes(int64_t Fi, int64_t Fo) {
 static size_t pack_bytes(int64_t Fi, int64_t Fo) {
   return pack_f32_bytes(Fi, Fo) + gs_align_up((size_t)(3 * 2 * Fi * Fo) * sizeof(uint16_t), 256);
 }
-// GSAGE_WIDE_GEMM=f32 keeps the 128/256-wide layers on the fp32 MFMA kernels, =split puts all of
-// them on the bf16-split kernels (A/B measurements, tests); unset: chosen by shape
+// GSAGE_WIDE_GEMM=f32 keeps the wide layers on the fp32 MFMA kernels, =split puts every 256-column
+// tile on the bf16-split kernel whatever its K (A/B measurements, tests); unset: chosen by shape
 static int wide_gemm_mode() {
   static const int v = [] {
     const char *e = getenv("GSAGE_WIDE_GEMM");
@@ -1466,15 +1463,12 @@ static int wide_gemm_mode() {
 static int launch_wide(int ncols, const GemmArgs &a, void *pack_base, int64_t Fi, int64_t Fo,
                        hipStream_t st) {
   uint16_t *planes = (uint16_t *)((char *)pack_base + pack_f32_bytes(Fi, Fo));
-  // the split kernel runs one workgroup per CU (147 KB of LDS), so its prologue, epilogue and
-  // barriers are not hidden by a second workgroup: it wins where the K loop is long and the tile
-  // wide (256 -> 256 at 10 M rows: 16.0 vs 22.8 ms, with the L2 norm 18.7 vs 24.1 ms) and loses
-  // on short loops (128-wide with the L2-norm epilogue: 8.3 vs 7.9 ms)
-  const int split = wide_gemm_mode();
-  if (split == 0 || (split < 0 && (ncols < 256 || a.K < 256)))
-    return ncols == 128 ? launch_gemm_wide<1>(a, st) : launch_gemm_wide<2>(a, st);
-  return ncols == 128 ? launch_gemm_wide_split<1>(a, planes, st)
-                      : launch_gemm_wide_split<2>(a, planes, st);
+  // the split kernel exists for 256-column tiles; it wins where the K loop is long (256 -> 256 at
+  // 10 M rows: 14.7 vs 22.8 ms, with the L2 norm 15.7 vs 24.1 ms); short loops keep the fp32 kernel
+  const int mode = wide_gemm_mode();
+  if (ncols % 256 == 0 && mode != 0 && (mode == 1 || a.K >= 256))
+    return launch_gemm_split256(a, planes, st);
+  return ncols == 128 ? launch_gemm_wide<1>(a, st) : launch_gemm_wide<2>(a, st);
 }
 
 extern "C" size_t gsage_project_workspace_bytes(int64_t Fi, int64_t Fo) {
