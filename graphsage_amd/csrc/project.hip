@@ -516,8 +516,9 @@ __global__ void split_planes_k(const float *__restrict__ bp, int total, uint16_t
 // workgroup of the CU computes while this one stages.  (Measured and dropped: 16-k steps with the
 // two halves of the stage double-buffered and the DMA issued a step ahead -- one barrier per 48
 // MFMAs instead of two per 96 -- 17.1 ms against 14.7 ms per 256 -> 256 layer at 10 M rows.)
-__global__ void __launch_bounds__(256, 2) gemm_split256_k(GemmArgs a, const uint16_t *__restrict__ Bpl) {
-  constexpr int BM = 128, BN = 256, TM = 2, TN = 4;
+template <int TN>   // 32-column blocks per wave: 4 -> 256-column tiles, 2 -> 128-column tiles
+__global__ void __launch_bounds__(256, 2) gemm_split_k(GemmArgs a, const uint16_t *__restrict__ Bpl) {
+  constexpr int BM = 128, BN = 64 * TN, TM = 2;
   constexpr int NA = BM * 8 / 256;                       // float4 of A per thread per chunk
   constexpr int PLANE = (BM + BN) * 32;                  // bf16 per plane (A rows, then B rows)
   extern __shared__ __align__(16) uint16_t s256_smem[];  // 3 planes + rowss
@@ -582,7 +583,7 @@ __global__ void __launch_bounds__(256, 2) gemm_split256_k(GemmArgs a, const uint
 #define S256_GLDS_B(KC)                                                                       \
   {                                                                                           \
     _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                          \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                         \
+      _Pragma("unroll") for (int q = 0; q < TN; ++q) {                                        \
         const int blk = q * 4 + w;                                                            \
         const int n = blk * 16 + (lane >> 2);                                                 \
         const int sl = (lane & 3) ^ ((n >> 2) & 3);                                           \
@@ -649,16 +650,18 @@ __global__ void __launch_bounds__(256, 2) gemm_split256_k(GemmArgs a, const uint
   wide_epilogue<TN, 2>(acc, a, row0, n0, wm, wn, lane, rowss);
 }
 
-int launch_gemm_split256(const GemmArgs &a, uint16_t *planes, hipStream_t st) {
-  constexpr size_t lds = 3 * (size_t)(128 + 256) * 32 * sizeof(uint16_t) + 128 * 4 * sizeof(float);
+template <int TN>
+int launch_gemm_split(const GemmArgs &a, uint16_t *planes, hipStream_t st) {
+  constexpr int BN = 64 * TN;
+  constexpr size_t lds = 3 * (size_t)(128 + BN) * 32 * sizeof(uint16_t) + 128 * 4 * sizeof(float);
   static std::atomic<bool> done[64];
-  if (int rc = allow_dynamic_lds(gemm_split256_k, lds, done)) return rc;
+  if (int rc = allow_dynamic_lds(gemm_split_k<TN>, lds, done)) return rc;
   const int total = a.Ncols * a.K;
   hipLaunchKernelGGL(split_planes_k, dim3(gs_grid(total, 256, 256)), dim3(256), 0, st, a.Bp, total,
                      planes);
   GSAGE_CHECK_LAUNCH();
-  dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.Ncols / 256));
-  hipLaunchKernelGGL(gemm_split256_k, grid, dim3(256), lds, st, a, (const uint16_t *)planes);
+  dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.Ncols / BN));
+  hipLaunchKernelGGL((gemm_split_k<TN>), grid, dim3(256), lds, st, a, (const uint16_t *)planes);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }
@@ -1466,8 +1469,8 @@ static int launch_wide(int ncols, const GemmArgs &a, void *pack_base, int64_t Fi
   // the split kernel exists for 256-column tiles; it wins where the K loop is long (256 -> 256 at
   // 10 M rows: 14.7 vs 22.8 ms, with the L2 norm 15.7 vs 24.1 ms); short loops keep the fp32 kernel
   const int mode = wide_gemm_mode();
-  if (ncols % 256 == 0 && mode != 0 && (mode == 1 || a.K >= 256))
-    return launch_gemm_split256(a, planes, st);
+  if (mode != 0 && (mode == 1 || a.K >= 256))
+    return ncols == 128 ? launch_gemm_split<2>(a, planes, st) : launch_gemm_split<4>(a, planes, st);
   return ncols == 128 ? launch_gemm_wide<1>(a, st) : launch_gemm_wide<2>(a, st);
 }
 
