@@ -55,6 +55,7 @@ __device__ __forceinline__ float4 gather_range(const int *__restrict__ col,
                                                int p0, int p1) {
   constexpr int G = 64 / LPR;
   constexpr int NB = GATHER_NB;
+  static_assert(!(MASKED && WMODE == 2), "per-entry weights do not survive the compaction");
   const int lane = gs_lane();
   const int slot = lane / LPR, sub = lane % LPR;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
