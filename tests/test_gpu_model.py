@@ -273,3 +273,40 @@ def test_cached_input_aggregation_gives_identical_steps():
         a.zero_grad(), b.zero_grad()
     xg = x.clone().requires_grad_()
     assert torch.equal(a(xg, ei), b(xg, ei))               # features with grad: never cached
+
+
+@pytest.mark.parametrize("n,edges", [
+    (1, []),                                   # a single node, no edge
+    (5, []),                                   # several nodes, no edge at all
+    (3, [(0, 0), (1, 1), (2, 2)]),             # self loops only
+    (4, [(0, 1), (0, 1), (0, 1), (2, 3)]),     # a triplicated edge
+    (130, [(i, 129) for i in range(129)]),     # a star: one row with every other node as neighbour
+])
+def test_degenerate_graphs_forward_backward_and_loss(n, edges):
+    """Tiny and lopsided inputs: eval forward, a full training step's gradients and the loss on a
+    one-pair batch, all against the oracle."""
+    cfg = dict(in_channels=7, hidden_channels=64, out_channels=64, num_layers=2, dropout=0.0)
+    from graphsage_amd import SkipGramLoss
+    m, ref = _pair(cfg, seed=n)
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 7, generator=g)
+    ei = torch.tensor(edges, dtype=torch.int64).reshape(-1, 2).t().contiguous()
+    m.train(), ref.train()
+    t = torch.randint(0, n, (1,), generator=g)
+    c = torch.randint(0, n, (1,), generator=g)
+    neg = torch.randint(0, n, (1, 5), generator=g)
+    emb = m(x.cuda(), ei.cuda())
+    want = ref(x, ei)
+    assert_close(emb.detach().cpu(), want.detach())
+    loss = SkipGramLoss()(emb, t.cuda(), c.cuda(), neg.cuda())
+    ref_loss = O.skipgram_loss(want, t, c, neg)
+    assert_close(loss.detach().cpu(), ref_loss.detach())
+    loss.backward()
+    ref_loss.backward()
+    # absolute floor: with one node (or all indices equal) the true gradient is exactly zero --
+    # the loss gradient is parallel to the embedding and the L2-norm backward projects it out --
+    # so both sides hold rounding noise of ~1e-8 and a floor relative to max|want| means nothing
+    for (name, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        err = (p.grad.cpu().double() - q.grad.double()).abs()
+        tol = 1e-4 * q.grad.double().abs() + 1e-6
+        assert bool((err <= tol).all()), f"{name}: worst error {float(err.max()):.3e}"
