@@ -230,6 +230,8 @@ def main():
                        else "full graph every step (as the reference)",
                        "input_aggregation": "cached across steps (opt-in, not the reference's work)"
                        if args.cache_input_aggregation else "recomputed every step",
+                       "pairs": "target = source of a random edge, context = its 1-hop neighbour or "
+                                "(p = 1/2) a 2-hop one, negatives ~ out_degree^0.75",
                        "parallelism": f"replicated graph, pair-sharded dp{world}",
                        "loss_backward": "deterministic (sorted)" if ops.loss_bwd_deterministic(nodes, B, K)
                        else "atomic",
