@@ -40,8 +40,12 @@ SIGNATURES = {
     "gsage_project_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gsage_project_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int,
                                     C.c_float, _p, _p, _p, _p, _p, _p, _p, _sz, C.c_int, _p]),
-    "gsage_project_bwd_nz": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int,
-                                       C.c_float, _p, _p, _p, _p, _p, _p, _p, _sz, C.c_int, _p, _p]),
+    "gsage_relu_sign_bytes": (_sz, [_i64, _i64]),
+    "gsage_project_fwd_ex": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int, _p,
+                                       C.c_uint64, C.c_float, _p, _p, _p, C.c_int, _p, _p]),
+    "gsage_project_bwd_ex": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int,
+                                       C.c_float, _p, _p, _p, _p, _p, _p, _p, _sz, C.c_int, _p, _p,
+                                       _p]),
     "gsage_skipgram_workspace_bytes": (_sz, [_i64]),
     "gsage_skipgram_fwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, C.c_float,
                                      C.c_double, C.c_double, _p, _p, _p, _sz, _p]),

@@ -1063,7 +1063,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
                   const float *__restrict__ wt /* [16][Fo] */, int64_t N, int Fo, EpiArgs e,
-                  float *__restrict__ out) {
+                  float *__restrict__ out, uint64_t *__restrict__ sign) {
   constexpr int K16_PP = 68;                   // pitch of the 16 x 64 output patch
   __shared__ __align__(16) float patches[4][16 * K16_PP];
   float *patch = patches[threadIdx.x >> 6];
@@ -1141,9 +1141,23 @@ project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
       const int64_t orow = r0 + rr;
       const float4 o = *(const float4 *)(patch + rr * K16_PP + rl * 4);
       if (orow < N) *(float4 *)(out + orow * Fo + cb + rl * 4) = o;
+      if (sign) {
+        // which outputs are positive, for the backward's ReLU'/dropout' (gsage_relu_sign_words):
+        // per group of 4 rows and column block four 64-bit words, word c bit l = component c of
+        // lane l's float4 -- the lane layout dw16_mfma_k reads the rows back in
+        const unsigned long long b0 = __ballot(o.x > 0.f), b1 = __ballot(o.y > 0.f);
+        const unsigned long long b2 = __ballot(o.z > 0.f), b3 = __ballot(o.w > 0.f);
+        const unsigned long long mine = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+        const int64_t grp = (r0 >> 2) + i;
+        if (lane < 4 && r0 + 4 * i < N)
+          sign[((int64_t)blockIdx.y * ((N + 3) >> 2) + grp) * 4 + lane] = mine;
+      }
     }
   }
 }
+
+// the word behind the sign bits says whether the forward kernel that ran filled them in
+__global__ void sign_flag_k(uint64_t *flag, uint64_t v) { *flag = v; }
 
 // generic forward: wave per row, lanes stride the output columns; Wt from L1/L2.
 __global__ void __launch_bounds__(256)
@@ -1284,22 +1298,19 @@ dw_smallk_k(const float *__restrict__ dpre, const float *__restrict__ out_saved,
 constexpr int DW16_SLAB = 64 * 16 + 64;   // [m][k'] then bias[m]; k' < 8: agg col, else x col
 constexpr int DW16_BLOCKS = 256 * 4;
 
-__global__ void __launch_bounds__(256)
-dw16_mfma_k(const float *__restrict__ g, const float *__restrict__ y, int relu_mode,
-            float inv_keep, const float *__restrict__ agg, const float *__restrict__ x, int64_t M,
-            int Fi, int Fo, float *__restrict__ slabs) {
-  // blockIdx.y selects a block of 64 output columns (Fo = 64, 128, 256 ...)
-  g += blockIdx.y * 64;
-  y += blockIdx.y * 64;
-  __shared__ float red[4][17][64];
-  const int lane = gs_lane(), wave = threadIdx.x >> 6;
+// the row loop of dw16_mfma_k; BITS: ReLU'/dropout' from the forward's sign bits (one uniform
+// 32-byte read per 4 rows) instead of the saved output rows (both loops free of branches around
+// their loads)
+template <bool BITS>
+__device__ __forceinline__ void dw16_rows(const float *__restrict__ g, const float *__restrict__ y,
+                                          const uint64_t *__restrict__ sg, int relu_mode,
+                                          float inv_keep, const float *__restrict__ agg,
+                                          const float *__restrict__ x, int64_t M, int Fi, int Fo,
+                                          int64_t wave0, int64_t nwaves, f32x4 (&acc)[4],
+                                          float4 &bacc) {
+  const int lane = gs_lane();
   const int slot = lane >> 4, sub = lane & 15;
-  f32x4 acc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t ngroups = (M + 3) >> 2;
   constexpr int U = 4;   // 4 row groups (16 rows) in flight per wave
   for (int64_t r0 = wave0 * (4 * U); r0 < M; r0 += nwaves * (4 * U)) {
     float4 d[U], yv[U];
@@ -1309,8 +1320,16 @@ dw16_mfma_k(const float *__restrict__ g, const float *__restrict__ y, int relu_m
       int64_t row = r0 + u * 4 + slot;
       bool live = row < M;
       d[u] = live ? *(const float4 *)(g + row * Fo + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      yv[u] = (live && relu_mode) ? *(const float4 *)(y + row * Fo + sub * 4)
-                                  : make_float4(1.f, 1.f, 1.f, 1.f);
+      if (BITS) {
+        int64_t grp = (r0 >> 2) + u;
+        grp = grp < ngroups ? grp : 0;          // rows past M carry a zero gradient anyway
+        const uint64_t *w4 = sg + grp * 4;
+        yv[u] = make_float4((float)((w4[0] >> lane) & 1ull), (float)((w4[1] >> lane) & 1ull),
+                            (float)((w4[2] >> lane) & 1ull), (float)((w4[3] >> lane) & 1ull));
+      } else {
+        yv[u] = (live && relu_mode) ? *(const float4 *)(y + row * Fo + sub * 4)
+                                    : make_float4(1.f, 1.f, 1.f, 1.f);
+      }
       float av = 0.f;
       if (live) {
         if (sub < 8) { if (sub < Fi) av = agg[row * Fi + sub]; }
@@ -1332,6 +1351,33 @@ dw16_mfma_k(const float *__restrict__ g, const float *__restrict__ y, int relu_m
       bacc.x += v.x; bacc.y += v.y; bacc.z += v.z; bacc.w += v.w;
     }
   }
+}
+
+__global__ void __launch_bounds__(256)
+dw16_mfma_k(const float *__restrict__ g, const float *__restrict__ y, int relu_mode,
+            float inv_keep, const float *__restrict__ agg, const float *__restrict__ x, int64_t M,
+            int Fi, int Fo, float *__restrict__ slabs, const uint64_t *__restrict__ sign) {
+  // blockIdx.y selects a block of 64 output columns (Fo = 64, 128, 256 ...)
+  g += blockIdx.y * 64;
+  y += blockIdx.y * 64;
+  __shared__ float red[4][17][64];
+  const int lane = gs_lane(), wave = threadIdx.x >> 6;
+  const int slot = lane >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  // the forward's sign bits, when it left them (flag word behind them), replace the 256-byte
+  // read of the saved output row by 32 bytes per 4 rows
+  const int64_t ngroups = (M + 3) >> 2;
+  const bool bits = relu_mode && sign && sign[(int64_t)gridDim.y * ngroups * 4] != 0ull;
+  if (bits)
+    dw16_rows<true>(g, y, sign + (int64_t)blockIdx.y * ngroups * 4, 1, inv_keep, agg, x, M, Fi, Fo,
+                    wave0, nwaves, acc, bacc);
+  else
+    dw16_rows<false>(g, y, nullptr, relu_mode, inv_keep, agg, x, M, Fi, Fo, wave0, nwaves, acc, bacc);
   bacc.x += __shfl_xor(bacc.x, 16, 64); bacc.y += __shfl_xor(bacc.y, 16, 64);
   bacc.z += __shfl_xor(bacc.z, 16, 64); bacc.w += __shfl_xor(bacc.w, 16, 64);
   bacc.x += __shfl_xor(bacc.x, 32, 64); bacc.y += __shfl_xor(bacc.y, 32, 64);
@@ -1479,11 +1525,17 @@ extern "C" size_t gsage_project_workspace_bytes(int64_t Fi, int64_t Fo) {
   return pack_bytes(Fi, Fo);
 }
 
-extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *w_l,
-                                 const float *b_l, const float *w_r, int64_t N, int64_t Fi,
-                                 int64_t Fo, int epilogue, const uint8_t *keep_mask,
-                                 uint64_t seed, float p, float *out, float *rnorm, void *wpack,
-                                 int force_generic, gsage_stream_t stream) {
+extern "C" size_t gsage_relu_sign_bytes(int64_t N, int64_t Fo) {
+  if (N < 0 || Fo <= 0) return 0;
+  return (size_t)(((N + 3) / 4) * 4 * ((Fo + 63) / 64) + 1) * sizeof(uint64_t);
+}
+
+extern "C" int gsage_project_fwd_ex(const float *agg, const float *x, const float *w_l,
+                                    const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                                    int64_t Fo, int epilogue, const uint8_t *keep_mask,
+                                    uint64_t seed, float p, float *out, float *rnorm, void *wpack,
+                                    int force_generic, uint64_t *relu_sign,
+                                    gsage_stream_t stream) {
   if (N < 0 || Fi <= 0 || Fo <= 0 || !agg || !x || !w_l || !b_l || !w_r || !out || !wpack)
     return GSAGE_ERR_INVALID_ARG;
   if (epilogue < GSAGE_EPI_NONE || epilogue > GSAGE_EPI_L2NORM) return GSAGE_ERR_INVALID_ARG;
@@ -1491,6 +1543,13 @@ extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *
   if (Fi > 16384 || Fo > 16384) return GSAGE_ERR_UNSUPPORTED;
   if (N == 0) return GSAGE_OK;
   hipStream_t st = gs_stream(stream);
+  // only the first-layer MFMA kernel leaves sign bits; the word behind them tells the backward
+  bool sign_written = false;
+  uint64_t *sign_flag = relu_sign ? relu_sign + ((N + 3) / 4) * 4 * ((Fo + 63) / 64) : nullptr;
+  if (sign_flag) {
+    hipLaunchKernelGGL(sign_flag_k, dim3(1), dim3(1), 0, st, sign_flag, (uint64_t)0);
+    GSAGE_CHECK_LAUNCH();
+  }
   EpiArgs e{};
   e.mode = epilogue;
   e.bias = b_l;
@@ -1526,8 +1585,10 @@ extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *
   if (force_generic == 0 && Fi == 8 && Fo % 64 == 0 && (Fo == 64 || epilogue != GSAGE_EPI_L2NORM) &&
       ((((uintptr_t)agg | (uintptr_t)x | (uintptr_t)out | (uintptr_t)b_l | (uintptr_t)keep_mask) & 15) == 0)) {
     int g16 = gs_grid(N, 64, 256 * 8);
+    const bool relu = epilogue == GSAGE_EPI_RELU || epilogue == GSAGE_EPI_RELU_DROPOUT;
     hipLaunchKernelGGL(project_fwd_k16_k, dim3(g16, fo / 64), dim3(256), 0, st, agg, x, wp, N, fo, e,
-                       out);
+                       out, relu ? relu_sign : nullptr);
+    sign_written = relu;
   } else if (2 * Fi <= 16 && (Fo <= 64 || (Fo % 64 == 0 && epilogue != GSAGE_EPI_L2NORM)))
     hipLaunchKernelGGL((project_fwd_smallk_k<16>), dim3(grid, (fo + 63) / 64), dim3(256), 0, st, agg,
                        x, wp, N, fi, fo, e, out);
@@ -1535,7 +1596,20 @@ extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *
     hipLaunchKernelGGL(project_fwd_generic_k, dim3(grid), dim3(256), 0, st, agg, x, wp, N, fi, fo,
                        e, out);
   GSAGE_CHECK_LAUNCH();
+  if (sign_flag && sign_written) {
+    hipLaunchKernelGGL(sign_flag_k, dim3(1), dim3(1), 0, st, sign_flag, (uint64_t)1);
+    GSAGE_CHECK_LAUNCH();
+  }
   return GSAGE_OK;
+}
+
+extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *w_l,
+                                 const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                                 int64_t Fo, int epilogue, const uint8_t *keep_mask,
+                                 uint64_t seed, float p, float *out, float *rnorm, void *wpack,
+                                 int force_generic, gsage_stream_t stream) {
+  return gsage_project_fwd_ex(agg, x, w_l, b_l, w_r, N, Fi, Fo, epilogue, keep_mask, seed, p, out,
+                              rnorm, wpack, force_generic, nullptr, stream);
 }
 
 extern "C" size_t gsage_project_bwd_workspace_bytes(int64_t N, int64_t Fi, int64_t Fo) {
@@ -1551,13 +1625,14 @@ static __global__ void __launch_bounds__(256) fill_words_k(uint32_t *p, int64_t 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) p[i] = v;
 }
 
-extern "C" int gsage_project_bwd_nz(const float *grad_out, const float *out, const float *rnorm,
+extern "C" int gsage_project_bwd_ex(const float *grad_out, const float *out, const float *rnorm,
                                     const float *agg, const float *x, const float *w_l,
                                     const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
                                     int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
                                     float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
                                     void *ws, size_t ws_bytes, int force_generic,
-                                    uint32_t *nz_mask, gsage_stream_t stream) {
+                                    uint32_t *nz_mask, const uint64_t *relu_sign,
+                                    gsage_stream_t stream) {
   if (N < 0 || Fi <= 0 || Fo <= 0 || !grad_out || !agg || !x || !w_l || !w_r || !grad_w_l ||
       !grad_b || !grad_w_r || !ws)
     return GSAGE_ERR_INVALID_ARG;
@@ -1653,7 +1728,7 @@ extern "C" int gsage_project_bwd_nz(const float *grad_out, const float *out, con
     int ncb = fo / 64;
     int grid = gs_grid(N, 64, DW16_BLOCKS / ncb);
     hipLaunchKernelGGL(dw16_mfma_k, dim3(grid, ncb), dim3(256), 0, st, dp, out, fuse_relu ? 1 : 0,
-                       inv_keep, agg, x, N, fi, fo, slabs);
+                       inv_keep, agg, x, N, fi, fo, slabs, fuse_relu ? relu_sign : nullptr);
     GSAGE_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_dw16_k, dim3((DW16_SLAB + 63) / 64, ncb), dim3(256), 0, st, slabs,
                        grid, fi, grad_w_l, grad_w_r, grad_b);
@@ -1686,7 +1761,7 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
                                  float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
                                  void *ws, size_t ws_bytes, int force_generic,
                                  gsage_stream_t stream) {
-  return gsage_project_bwd_nz(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, N, Fi, Fo, epilogue,
+  return gsage_project_bwd_ex(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, N, Fi, Fo, epilogue,
                               p, dpre, grad_agg, grad_x, grad_w_l, grad_b, grad_w_r, ws, ws_bytes,
-                              force_generic, nullptr, stream);
+                              force_generic, nullptr, nullptr, stream);
 }

@@ -118,7 +118,10 @@ def aggregate_mean_bwd(graph: GraphCSR, grad_agg: torch.Tensor, prescaled: bool 
 
 
 def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0, p=0.0,
-                force_generic=False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                force_generic=False, want_relu_sign: bool = False, alloc_relu_sign: bool = True):
+    """K3 forward -> (out, rnorm).  With ``want_relu_sign`` a third value is returned: the buffer
+    of ``out > 0`` bits the first-layer kernel leaves for :func:`project_bwd` (None for shapes
+    and epilogues that have no use for it, or when ``alloc_relu_sign`` is off)."""
     lib = _lib.load()
     N, Fi = x.shape
     Fo = w_l.shape[0]
@@ -131,12 +134,18 @@ def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0
             if keep_mask.dtype != torch.uint8 or tuple(keep_mask.shape) != (N, Fo):
                 raise ValueError("keep_mask must be uint8 [N, Fo]")
             keep_mask = keep_mask.contiguous()
-        rc = lib.gsage_project_fwd(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), b_l.data_ptr(),
-                                   w_r.data_ptr(), N, Fi, Fo, int(epilogue), _lib.ptr(keep_mask),
-                                   int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), out.data_ptr(),
-                                   _lib.ptr(rnorm), wpack.data_ptr(), int(force_generic),
-                                   _lib.stream_handle())
+        sign = None
+        if want_relu_sign and alloc_relu_sign and Fi <= 8 and Fo % 64 == 0 and epilogue in (_lib.EPI_RELU,
+                                                                       _lib.EPI_RELU_DROPOUT):
+            sign = torch.empty(lib.gsage_relu_sign_bytes(N, Fo) // 8, dtype=torch.int64, device=dev)
+        rc = lib.gsage_project_fwd_ex(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), b_l.data_ptr(),
+                                      w_r.data_ptr(), N, Fi, Fo, int(epilogue), _lib.ptr(keep_mask),
+                                      int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), out.data_ptr(),
+                                      _lib.ptr(rnorm), wpack.data_ptr(), int(force_generic),
+                                      _lib.ptr(sign), _lib.stream_handle())
     _lib.check(rc, "gsage_project_fwd")
+    if want_relu_sign:
+        return out, rnorm, sign
     return out, rnorm
 
 
@@ -147,7 +156,8 @@ SKIP_ZERO_ROWS = os.environ.get("GSAGE_SKIP_ZERO_ROWS", "1") != "0"
 
 
 def project_bwd(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue, p,
-                need_input_grad: bool, force_generic=False, want_nz_mask: bool = False):
+                need_input_grad: bool, force_generic=False, want_nz_mask: bool = False,
+                relu_sign: Optional[torch.Tensor] = None):
     """Backward of K3.  With ``want_nz_mask`` a sixth value is returned: the int32 bit mask of the
     possibly non-zero rows of grad_agg / grad_x (None when the shape has no kernel that finds it)."""
     lib = _lib.load()
@@ -167,13 +177,15 @@ def project_bwd(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue, p,
         nz = None
         if want_nz_mask and need_input_grad and Fi == 64 and Fo == 64:
             nz = torch.empty((N + 31) // 32, dtype=torch.int32, device=dev)
-        rc = lib.gsage_project_bwd_nz(grad_out.data_ptr(), _lib.ptr(out), _lib.ptr(rnorm),
+        if relu_sign is not None and relu_sign.numel() * 8 != lib.gsage_relu_sign_bytes(N, Fo):
+            raise ValueError("relu_sign does not belong to a forward of this shape")
+        rc = lib.gsage_project_bwd_ex(grad_out.data_ptr(), _lib.ptr(out), _lib.ptr(rnorm),
                                       agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), w_r.data_ptr(),
                                       _lib.ptr(agg_scale), N, Fi, Fo, int(epilogue), float(p),
                                       _lib.ptr(dpre), _lib.ptr(grad_agg), _lib.ptr(grad_x),
                                       gwl.data_ptr(), gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(),
                                       ws_bytes, int(force_generic), _lib.ptr(nz),
-                                      _lib.stream_handle())
+                                      _lib.ptr(relu_sign), _lib.stream_handle())
     _lib.check(rc, "gsage_project_bwd")
     if want_nz_mask:
         return grad_agg, grad_x, gwl, gb, gwr, nz
@@ -269,14 +281,19 @@ class SAGELayerFunction(torch.autograd.Function):
         if w_l.shape != w_r.shape or w_l.size(1) != x.size(1) or b_l.numel() != w_l.size(0):
             raise ValueError("SAGEConv weight shapes do not match the input width")
         agg = agg_cached if agg_cached is not None else aggregate_mean(graph, x)
-        out, rnorm = project_fwd(agg, x, w_l, b_l, w_r, epilogue, keep_mask, seed, p, force_generic)
+        # sign bits of the output for the backward, wanted only where the backward stops at this
+        # layer's weights (the first layer): then ReLU'/dropout' is applied inside the dW kernel
+        want_sign = not (ctx.needs_input_grad[0] or ctx.needs_input_grad[10])
+        out, rnorm, sign = project_fwd(agg, x, w_l, b_l, w_r, epilogue, keep_mask, seed, p,
+                                       force_generic, want_relu_sign=True,
+                                       alloc_relu_sign=want_sign)
         ctx.graph, ctx.epilogue, ctx.p, ctx.force_generic = graph, epilogue, p, force_generic
-        ctx.save_for_backward(x, agg, out, rnorm, w_l, w_r)
+        ctx.save_for_backward(x, agg, out, rnorm, w_l, w_r, sign)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, agg, out, rnorm, w_l, w_r = ctx.saved_tensors
+        x, agg, out, rnorm, w_l, w_r, sign = ctx.saved_tensors
         graph = ctx.graph
         need_x = ctx.needs_input_grad[0]
         grad_out = _f32c(grad_out, "grad_out")
@@ -289,7 +306,7 @@ class SAGELayerFunction(torch.autograd.Function):
             return (grad_x if need_x else None), gwl, gb, gwr, None, None, None, None, None, None, grad_agg
         grad_agg, grad_x, gwl, gb, gwr, nz = project_bwd(
             grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p,
-            need_x, ctx.force_generic, want_nz_mask=True)
+            need_x, ctx.force_generic, want_nz_mask=True, relu_sign=sign)
         if need_x:
             # grad_agg arrives pre-scaled by inv_deg[row]; gather it over the transposed CSR
             grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x,

@@ -100,7 +100,7 @@ int gsage_segment_gather(const int32_t *rowptr, const int32_t *col,
  * CLEAR bit promises that row r of x is all zero, so it is not fetched.  In the training step the
  * gradient that reaches the layer-2 backward is non-zero only on the rows the pair batch
  * touched (PyG's backward scatters those zero rows like any other: graphsage.py:138 under
- * autograd); gsage_project_bwd_nz produces the mask.  NULL => gsage_segment_gather.  The live
+ * autograd); gsage_project_bwd_ex produces the mask.  NULL => gsage_segment_gather.  The live
  * neighbours of a row are compacted before they are summed, so sums may differ from the
  * unmasked call in the last bit (the order is still fixed for a given mask). */
 int gsage_segment_gather_skip(const int32_t *rowptr, const int32_t *col,
@@ -156,16 +156,32 @@ int gsage_project_bwd(const float *grad_out, const float *out, const float *rnor
                       float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
                       void *ws, size_t ws_bytes, int force_generic,
                       gsage_stream_t stream);
-/* Same, and also writes nz_mask: uint32 [ceil(N/32)], bit r%32 of word r/32 is CLEAR only if
- * row r of dpre (hence of grad_agg and grad_x) is all zero.  The fused 64 -> 64 kernel tests the
- * rows as it stages them; every other shape reports all rows as possibly non-zero. */
-int gsage_project_bwd_nz(const float *grad_out, const float *out, const float *rnorm,
+/* The same pair with two optional side channels between a forward and its backward (both may be
+ * NULL; neither changes a result):
+ *   nz_mask   (bwd out): uint32 [ceil(N/32)], bit r%32 of word r/32 is CLEAR only if row r of dpre
+ *             (hence of grad_agg and grad_x) is all zero.  The fused 64 -> 64 kernel tests the rows
+ *             as it walks them; every other shape reports all rows as possibly non-zero.  Feeds
+ *             gsage_segment_gather_skip.
+ *   relu_sign (fwd out, bwd in): gsage_relu_sign_bytes(N, Fo) bytes.  For the RELU / RELU_DROPOUT
+ *             epilogues the first-layer MFMA kernel (Fi = 8) leaves one bit per output element,
+ *             set where out > 0, and the first-layer dW kernel reads those 8 bytes per row
+ *             instead of the 256-byte row of `out` (autograd keeps and re-reads the whole
+ *             activation for relu'/dropout': graphsage.py:134-135).  The last word says whether
+ *             the bits were written; forward kernels that do not write them clear it, and the
+ *             backward then reads `out` as usual. */
+size_t gsage_relu_sign_bytes(int64_t N, int64_t Fo);
+int gsage_project_fwd_ex(const float *agg, const float *x, const float *w_l,
+                         const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                         int64_t Fo, int epilogue, const uint8_t *keep_mask,
+                         uint64_t seed, float p, float *out, float *rnorm, void *wpack,
+                         int force_generic, uint64_t *relu_sign, gsage_stream_t stream);
+int gsage_project_bwd_ex(const float *grad_out, const float *out, const float *rnorm,
                          const float *agg, const float *x, const float *w_l,
                          const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
                          int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
                          float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
                          void *ws, size_t ws_bytes, int force_generic, uint32_t *nz_mask,
-                         gsage_stream_t stream);
+                         const uint64_t *relu_sign, gsage_stream_t stream);
 
 /* ---------------------------------------------------------- K4 / K5: skip-gram loss
  * K4 replaces SkipGramLoss.forward / forward_with_details (src/model/loss.py:97-136,

@@ -182,3 +182,44 @@ def test_wide_shapes_on_both_kernel_families():
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, f"GSAGE_WIDE_GEMM={mode}:\n{r.stdout[-3000:]}\n{r.stderr[-1000:]}"
         assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_RELU, _lib.EPI_RELU_DROPOUT])
+@pytest.mark.parametrize("n,fi,fo", [(333, 8, 64), (4099, 8, 128), (64, 8, 256), (333, 5, 64), (1, 8, 64)])
+def test_relu_sign_bits_replace_the_saved_output(n, fi, fo, epi):
+    """gsage_project_fwd_ex / _bwd_ex: the first-layer kernel leaves `out > 0` bits, the dW kernel
+    uses them instead of the saved output and gives bit-identical weight gradients; forward
+    kernels that leave no bits (Fi != 8 here) say so and the backward reads `out` as before."""
+    from graphsage_amd.ops import project_bwd, project_fwd
+    agg, x, wl, bl, wr, keep, gout = _case(n, fi, fo, 7 * n + fo)
+    d = [t.cuda() for t in (agg, x, wl, bl, wr)]
+    p = 0.3 if epi == _lib.EPI_RELU_DROPOUT else 0.0
+    km = keep.cuda() if p else None
+    out, rnorm, sign = project_fwd(*d, epilogue=epi, keep_mask=km, p=p, want_relu_sign=True)
+    out0, _ = project_fwd(*d, epilogue=epi, keep_mask=km, p=p)
+    assert torch.equal(out, out0)
+    assert sign is not None and sign.dtype == torch.int64
+    ng, ncb = (n + 3) // 4, fo // 64
+    flag = int(sign[-1].item())
+    assert flag == (1 if fi == 8 else 0)
+    if flag:
+        # word c of (column block, 4-row group): bit l = (row 4g + l // 16, column 64cb + 4 (l % 16) + c)
+        w = sign[:-1].view(ncb, ng, 4)
+        bits = ((w[..., None] >> torch.arange(64, device="cuda")) & 1).bool()     # [cb, g, c, l]
+        pos = torch.zeros(ng * 4, fo, dtype=torch.bool, device="cuda")
+        pos[:n] = out > 0
+        want = pos.view(ng, 4, ncb, 16, 4).permute(2, 0, 4, 1, 3).reshape(ncb, ng, 4, 64)
+        live = (torch.arange(ng * 4, device="cuda") < n).view(ng, 4)[None, :, None, :, None]
+        live = live.expand(ncb, ng, 4, 4, 16).reshape(ncb, ng, 4, 64)
+        assert torch.equal(bits & live, want & live)
+    g = gout.cuda()
+    ref = project_bwd(g, out, rnorm, d[0], d[1], d[2], d[4], None, epi, p, False)
+    got = project_bwd(g, out, rnorm, d[0], d[1], d[2], d[4], None, epi, p, False, relu_sign=sign)
+    for a, b in zip(ref[2:], got[2:]):
+        assert torch.equal(a, b)
+    # the bits are what is read: a scrambled `out` must not change the weight gradients
+    if flag:
+        got2 = project_bwd(g, torch.full_like(out, -1.0), rnorm, d[0], d[1], d[2], d[4], None, epi, p,
+                           False, relu_sign=sign)
+        for a, b in zip(ref[2:], got2[2:]):
+            assert torch.equal(a, b)
