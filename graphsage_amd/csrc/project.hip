@@ -1512,10 +1512,11 @@ static int wide_gemm_mode() {
 static int launch_wide(int ncols, const GemmArgs &a, void *pack_base, int64_t Fi, int64_t Fo,
                        hipStream_t st) {
   uint16_t *planes = (uint16_t *)((char *)pack_base + pack_f32_bytes(Fi, Fo));
-  // the split kernel exists for 256-column tiles; it wins where the K loop is long (256 -> 256 at
-  // 10 M rows: 14.7 vs 22.8 ms, with the L2 norm 15.7 vs 24.1 ms); short loops keep the fp32 kernel
+  // the split kernels win where the K loop is long (256 -> 256 at 10 M rows: 14.7 vs 22.8 ms;
+  // 128 -> 128: 5.3 vs 6.7 ms) and tie on the shortest one in use (the dX GEMM of a 128-wide
+  // layer, K = 128), so every wide GEMM takes them unless GSAGE_WIDE_GEMM=f32 says otherwise
   const int mode = wide_gemm_mode();
-  if (mode != 0 && (mode == 1 || a.K >= 256))
+  if (mode != 0 && (mode == 1 || a.K >= 128))
     return ncols == 128 ? launch_gemm_split<2>(a, planes, st) : launch_gemm_split<4>(a, planes, st);
   return ncols == 128 ? launch_gemm_wide<1>(a, st) : launch_gemm_wide<2>(a, st);
 }
