@@ -1,5 +1,12 @@
-import sys, os, torch, time
-sys.path.insert(0, '/root/repo')
+"""Same number of edges over ever smaller node tables (10 M / 1 M / 100 k nodes): what perfect
+cache locality would buy the 8- and 64-wide gathers (quoted in DESIGN.md, K2)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from graphsage_amd import default_cache, ops
 from graphsage_amd.synth import powerlaw_graph
 for n, d in [(10_000_000, 20), (1_000_000, 200), (100_000, 2000)]:
