@@ -159,3 +159,56 @@ def test_oracle_snapshot(golden_dir):
     m = O.OracleGraphSAGE(7, 64, 64, 2, 0.3).eval()
     emb = m(torch.from_numpy(z["features"]), torch.from_numpy(z["edge_index"]))
     assert np.allclose(emb.detach().numpy(), s["embeddings"], rtol=1e-6, atol=1e-7)
+
+
+def test_two_layer_forward_against_exact_rational_arithmetic():
+    """An independent restatement of the spec in exact rational arithmetic,
+    plain Python loops, no torch op: mean over in-edges counted with multiplicity (self loops and
+    duplicates included, zero row for isolated nodes), lin_l with bias on the mean plus lin_r on
+    the node itself, ReLU between the layers.  Inputs are small integers and halves; the means
+    bring in thirds and fifths that float32 cannot hold, so the oracle is compared to 1e-6."""
+    from fractions import Fraction as Fr
+    import random
+    rnd = random.Random(7)
+    n, f0, f1, f2 = 9, 3, 4, 2
+    edges = [(rnd.randrange(n - 1), rnd.randrange(n - 1)) for _ in range(30)]   # node 8 isolated
+    edges += [(2, 2), (3, 5), (3, 5), (3, 5)]                                    # self loop, triple edge
+    x = [[Fr(rnd.randrange(-4, 5)) for _ in range(f0)] for _ in range(n)]
+    def mat(r, c):
+        return [[Fr(rnd.randrange(-3, 4), 2) for _ in range(c)] for _ in range(r)]
+    wl1, wr1, b1 = mat(f1, f0), mat(f1, f0), [Fr(rnd.randrange(-2, 3)) for _ in range(f1)]
+    wl2, wr2, b2 = mat(f2, f1), mat(f2, f1), [Fr(rnd.randrange(-2, 3)) for _ in range(f2)]
+
+    def conv(h, wl, b, wr):
+        width = len(h[0])
+        out = []
+        for i in range(n):
+            nb = [s for (s, t) in edges if t == i]
+            agg = [sum((h[s][k] for s in nb), Fr(0)) / max(len(nb), 1) for k in range(width)]
+            out.append([sum(wl[o][k] * agg[k] for k in range(width)) + b[o] +
+                        sum(wr[o][k] * h[i][k] for k in range(width)) for o in range(len(wl))])
+        return out
+
+    h1 = [[max(v, Fr(0)) for v in row] for row in conv(x, wl1, b1, wr1)]
+    pre = conv(h1, wl2, b2, wr2)
+
+    m = O.OracleGraphSAGE(f0, f1, f2, 2, dropout=0.0)
+    tf = lambda a: torch.tensor([[float(v) for v in row] for row in a], dtype=torch.float64)
+    with torch.no_grad():
+        m.convs[0].lin_l.weight.copy_(tf(wl1)); m.convs[0].lin_l.bias.copy_(tf([b1])[0])
+        m.convs[0].lin_r.weight.copy_(tf(wr1))
+        m.convs[1].lin_l.weight.copy_(tf(wl2)); m.convs[1].lin_l.bias.copy_(tf([b2])[0])
+        m.convs[1].lin_r.weight.copy_(tf(wr2))
+    m.eval()
+    ei = torch.tensor(edges, dtype=torch.int64).t().contiguous()
+    xs = tf(x).to(torch.float32)
+    m.normalize_output = False
+    got_pre = m(xs, ei).to(torch.float64)
+    want_pre = tf(pre)
+    # float32 cannot hold thirds and fifths exactly: 1e-6 relative on the un-normalised output
+    assert torch.allclose(got_pre, want_pre, rtol=1e-6, atol=1e-6)
+    m.normalize_output = True
+    got = m(xs, ei).to(torch.float64)
+    norms = want_pre.norm(dim=1, keepdim=True).clamp(min=1e-12)
+    assert torch.allclose(got, want_pre / norms, rtol=1e-6, atol=1e-6)
+    assert torch.equal(got[8] != 0, (want_pre[8] != 0))      # the isolated node still gets b_l + W_r x
