@@ -214,6 +214,10 @@ def main():
             "kernel": f"seg_gather_vec_k<{F // 4},0,masked>: rows whose gradient is zero are not fetched",
             "launches_timed": skip_launches, "mean_ms": skip_ms}
 
+    # fp32 storage and accumulation everywhere; the 128/256-wide GEMMs (C3) feed the bf16 matrix
+    # pipe with each fp32 operand split exactly into three bf16 parts (fp32-equivalent results)
+    dtype = "f32" if hidden < 128 or os.environ.get("GSAGE_WIDE_GEMM", "")[:1] == "f" else \
+        "f32 (wide GEMMs: bf16 MFMA on 3-way split fp32 operands, fp32 accumulate)"
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -223,7 +227,7 @@ def main():
             "metric": "co-occurrence pairs/sec trained (fwd+bwd+step)", "value": value,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": desc, "nodes": nodes, "edges": E, "negatives": K,
                        "pairs_per_gpu": B, "global_batch": B * world, "dropout": args.dropout,
                        "graph_pass": "2-hop closure of the batch only (opt-in)" if args.receptive_field
