@@ -14,7 +14,7 @@ from graphsage_amd.synth import powerlaw_graph
 
 def main():
     widths = [int(a) for a in sys.argv[1:]] or [8, 64, 128, 256]
-    n = 10_000_000
+    n = int(os.environ.get("PROBE_NODES", 10_000_000))
     ei = powerlaw_graph(n, 20, seed=42, device="cuda")
     E = ei.size(1)
     g = build_csr(ei, n)
