@@ -249,6 +249,57 @@ def test_full_size_c4_forward_and_weight_gradients_match_torch_composition():
         assert worst <= tol, (k, worst, tol)
 
 
+def test_c3_shape_forward_and_weight_gradients_match_float64_composition():
+    """C3 (1 M nodes, ~20 M edges, 7->128->128), eval mode: the 128-wide forward and the dX GEMM of
+    the backward run on the split-bf16 kernels; embeddings and all parameter gradients against
+    the float64 composition, same bars as the C4 test."""
+    from graphsage_amd.synth import memory_features, powerlaw_graph
+    n = 1_000_000
+    ei = powerlaw_graph(n, 20, seed=42, device="cuda")
+    x = memory_features(n, seed=42, device="cuda")
+    m, _ = _pair(CFGS[1], seed=0)
+    m.eval()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    probe = torch.randn(n, 128, device="cuda", generator=g) / n ** 0.5
+    emb = m(x, ei)
+    (emb * probe).sum().backward()
+    got = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    h = torch.relu(_torch_sage_gpu(x.double(), ei, m.convs[0], n))
+    want = torch.nn.functional.normalize(_torch_sage_gpu(h, ei, m.convs[1], n), p=2, dim=1)
+    del h
+    (want * probe.double()).sum().backward()
+    err = (emb.detach().double() - want.detach()).abs().max().item()
+    assert err <= 2e-6, err
+    for k, p in m.named_parameters():
+        ref = p.grad.double()
+        tol = (1e-5 if k.startswith("convs.1.") else 1e-3) * float(ref.abs().max())
+        worst = float((got[k].double() - ref).abs().max())
+        assert worst <= tol, (k, worst, tol)
+
+
+def test_c5_shape_forward_matches_float64_composition_at_scale():
+    """C5's model (3 layers, 256 wide, eval mode) on 2 M nodes / ~40 M edges: the 256-wide
+    projections run on the bf16 matrix pipe with three-way split fp32 operands; embeddings against
+    the same arithmetic composed from torch's GPU kernels in float64."""
+    from graphsage_amd.synth import memory_features, powerlaw_graph
+    n = 2_000_000
+    ei = powerlaw_graph(n, 20, seed=7, device="cuda")
+    x = memory_features(n, seed=7, device="cuda")
+    m, _ = _pair(CFGS[2], seed=3)
+    m.eval()
+    with torch.no_grad():
+        emb = m(x, ei)
+        h = x.double()
+        for conv in m.convs[:-1]:
+            h = torch.relu(_torch_sage_gpu(h, ei, conv, n))
+        want = torch.nn.functional.normalize(_torch_sage_gpu(h, ei, m.convs[-1], n), p=2, dim=1)
+    del h
+    err = (emb.double() - want).abs().max().item()
+    assert err <= 2e-6, err                                   # unit-norm rows: absolute = relative
+    assert torch.allclose(emb.norm(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
+
+
 def test_cached_input_aggregation_gives_identical_steps():
     """GraphSAGE(cache_input_aggregation=True): same embeddings and gradients bit for bit, and
     the cache follows in-place edits of the features (version counter)."""
