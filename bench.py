@@ -6,31 +6,43 @@ full-graph forward (2x SAGEConv, ReLU+dropout, L2 norm), skip-gram loss on this 
 pairs, backward, [gradient all-reduce over RCCL], clip_grad_norm_(1.0), Adam.  Graph, features
 and weights are replicated per GPU; pairs are sharded (weak scaling: pairs per GPU fixed).
 
-  python bench.py [--gpus N --steps K --warmup W] [--workload c4|c3|c2] [--pairs-per-gpu B]
+  python bench.py [--gpus N --steps K --warmup W] [--workload c4|c3|c2|c5] [--pairs-per-gpu B]
+
+`--gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process touches no GPU;
+it starts N ranks with `python -m torch.distributed.run` (one per GPU, RCCL), relays rank 0's
+single JSON line and exits non-zero when any rank fails or the line does not say N ranks.
+
+`--workload c5` is BASELINE config 5: one step = the full-graph inference encode of
+src/inference/encoder.py:181-185 (eval, no_grad, 3 layers x 256 wide) under the protocol of
+scripts/benchmark_latency.py:66-105; it does not shard (N > 1 = N replicas).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the
-dominant kernel (the F=64 segment gather of SAGEConv layer 2, forward + transposed backward)
-and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload).
+dominant kernel and `cpu_baseline` (the CPU oracle timed on a bounded sample of the workload).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (nodes, avg directed degree, hidden, out, description)
-    "c2": (100_000, 20, 64, 64, "C2: 100k-node/~2M-edge power-law graph, SAGE 7->64->64"),
-    "c3": (1_000_000, 20, 128, 128, "C3: 1M-node/~20M-edge power-law graph, SAGE 7->128->128"),
-    "c4": (10_000_000, 20, 64, 64, "C4: 10M-node/~200M-edge power-law graph, SAGE 7->64->64"),
+    # name: (nodes, avg directed degree, hidden, out, layers, description)
+    "c2": (100_000, 20, 64, 64, 2, "C2: 100k-node/~2M-edge power-law graph, SAGE 7->64->64"),
+    "c3": (1_000_000, 20, 128, 128, 2, "C3: 1M-node/~20M-edge power-law graph, SAGE 7->128->128"),
+    "c4": (10_000_000, 20, 64, 64, 2, "C4: 10M-node/~200M-edge power-law graph, SAGE 7->64->64"),
+    "c5": (10_000_000, 20, 256, 256, 3, "C5: full-graph inference encode, 10M-node/~200M-edge "
+                                        "power-law graph, SAGE 7->256->256->256 + L2 norm"),
 }
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
+MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 matrix peak (no sparsity)
+MFMA_F32_PEAK_TFS = 157.3    # fp32-input matrix peak
+SELFTEST = os.environ.get("GSAGE_BENCH_DIST_SELFTEST") == "1"   # CPU test of the launch path
 
 
 def log(msg):
@@ -38,40 +50,217 @@ def log(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def measured_traffic(workload, F):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c4")
+    ap.add_argument("--pairs-per-gpu", type=int, default=1 << 20)
+    ap.add_argument("--negatives", type=int, default=5)
+    ap.add_argument("--dropout", type=float, default=0.3)
+    ap.add_argument("--nodes", type=int, default=0,
+                    help="override the workload's node count (development runs; labelled)")
+    ap.add_argument("--cpu-nodes", type=int, default=200_000)
+    ap.add_argument("--cpu-steps", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-batch", action="store_true",
+                    help="skip the short second loop at the reference's batch of 1024 pairs")
+    ap.add_argument("--receptive-field", action="store_true",
+                    help="opt-in extra (not the headline): compute only the 2-hop closure of each "
+                         "batch (pays for small batches on large graphs)")
+    ap.add_argument("--cache-input-aggregation", action="store_true",
+                    help="opt-in extra (not the headline): keep mean_j x_j of the constant input "
+                         "features across steps instead of recomputing it like the reference")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------ N > 1 without a launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """Parent of an N-rank run.  Makes NO GPU call: the ranks are fresh child processes of
+    `python -m torch.distributed.run` (one per GPU, LOCAL_RANK set by the launcher).  Relays the
+    one JSON line rank 0 prints; returns the exit code (non-zero if any rank failed, if there is
+    not exactly one line, or if the line does not report N ranks)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "16")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd[1:8])} ...",
+          file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for raw in proc.stdout:
+        raw = raw.strip()
+        if raw.startswith("{") and '"metric"' in raw:
+            lines.append(raw)
+        elif raw:
+            print(raw, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"[bench] FAILED: the {n}-rank run exited with status {rc}; no result line",
+              file=sys.stderr, flush=True)
+        return rc if 0 < rc < 256 else 1
+    if len(lines) != 1:
+        print(f"[bench] FAILED: expected one result line from rank 0, got {len(lines)}",
+              file=sys.stderr, flush=True)
+        return 3
+    rec = json.loads(lines[0])
+    if rec.get("n_gpus") != n or rec.get("ranks_seen") != n:
+        print(f"[bench] FAILED: asked for {n} ranks, the line reports n_gpus={rec.get('n_gpus')} "
+              f"ranks_seen={rec.get('ranks_seen')}", file=sys.stderr, flush=True)
+        return 4
+    print(lines[0], flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------- rank-side set-up
+class Ranks:
+    """This process's place in the job and the collectives the bench itself needs."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world_env = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # rehearsal switch for a one-GPU box: all ranks on cuda:0 over gloo (RCCL needs one GPU
+        # per rank)
+        self.rehearse = os.environ.get("GSAGE_BENCH_REHEARSE_ONE_GPU") == "1"
+        self.backend = None
+        if self.rehearse:
+            import faulthandler
+            faulthandler.dump_traceback_later(300, exit=True)
+            self.local_rank = 0
+        if self.world_env > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.rehearse or SELFTEST:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world_env)
+            else:
+                if torch.cuda.device_count() <= self.local_rank:
+                    raise RuntimeError(f"rank {self.rank}: LOCAL_RANK {self.local_rank} but only "
+                                       f"{torch.cuda.device_count()} GPU(s) visible")
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world_env,
+                                        device_id=torch.device(f"cuda:{self.local_rank}"))
+            self.backend = dist.get_backend()
+        self.world = dist.get_world_size() if self.world_env > 1 else 1
+        if args.gpus != self.world:
+            raise SystemExit(f"[bench] --gpus {args.gpus} but the process group has {self.world} "
+                             f"rank(s): refusing to print a result line")
+        self.dev = torch.device("cpu") if SELFTEST else torch.device(f"cuda:{self.local_rank}")
+        if not SELFTEST:
+            torch.cuda.set_device(self.dev)
+        # gloo rehearsal / self-test: the bench's own small collectives go through host tensors
+        self.coll_dev = torch.device("cpu") if (self.rehearse or SELFTEST) else self.dev
+        self._token = torch.zeros(1, device=self.coll_dev)
+
+    def device_sync(self):
+        if not SELFTEST:
+            self.torch.cuda.synchronize()
+
+    def sync_all(self):
+        """barrier + device synchronize on both sides (the barrier is a one-element all-reduce)."""
+        self.device_sync()
+        if self.world > 1:
+            self.dist.all_reduce(self._token)
+            self.device_sync()
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def count_ranks(self):
+        """Every rank adds 1: the number of processes that really took part."""
+        if self.world == 1:
+            return 1
+        t = self.torch.ones(1, dtype=self.torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(t)
+        return int(round(float(t.item())))
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------ provenance
+def csrc_hash():
+    """sha256 over the kernel sources libgsage.so is built from (names + contents, sorted)."""
+    d = os.path.join(ROOT, "graphsage_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
     (profiles/*_pmc_hbm.json: separate FETCH_SIZE and WRITE_SIZE runs of this same command).
-    gfx950 correction: FETCH_SIZE counts 128-B read requests as 64 B, so it is doubled."""
+    gfx950 correction: FETCH_SIZE counts 128-B read requests as 64 B, so it is doubled.
+    Returns (bytes | None, file | None, stale): stale = the file was taken with other kernel
+    sources than the ones this run's library was built from (or does not say)."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_hbm.json"))):
         best = path
     if best is None:
-        return None, None
+        return None, None, None
     try:
         z = json.load(open(best))
-        k = f"seg_gather_vec_k<{F // 4}, 0, false>"      # the plain (unmasked) gather
-        fetch_kb, write_kb = z["FETCH_SIZE"][k]["mean_KB"], z["WRITE_SIZE"][k]["mean_KB"]
-        return (2.0 * fetch_kb + write_kb) * 1024.0, os.path.relpath(best, ROOT)
+        fetch_kb, write_kb = z["FETCH_SIZE"][kernel]["mean_KB"], z["WRITE_SIZE"][kernel]["mean_KB"]
+        stale = z.get("csrc_hash") != csrc_hash()
+        return (2.0 * fetch_kb + write_kb) * 1024.0, os.path.relpath(best, ROOT), stale
     except (KeyError, ValueError, OSError):
-        return None, None
+        return None, None, None
 
 
-def cpu_baseline(args, hidden, out_dim, K):
+# ---------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(args, hidden, out_dim, layers, K, inference=False):
     """The CPU oracle (oracle/sage_oracle.py: the op sequence PyG + loss.py execute on CPU,
     plus clip + Adam) on a bounded sample: the same generator at `--cpu-nodes` nodes with the
     pair batch scaled by the same factor, so pairs per node per step match the GPU workload."""
+    import torch
     from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
     from oracle import sage_oracle as O
     threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
     torch.set_num_threads(threads)
     n = args.cpu_nodes
-    nodes_full = WORKLOADS[args.workload][0]
-    b = max(1024, int(args.pairs_per_gpu * n / nodes_full))
+    nodes_full = args.nodes or WORKLOADS[args.workload][0]
     ei = powerlaw_graph(n, WORKLOADS[args.workload][1], seed=42)
     x = memory_features(n, seed=42)
     torch.manual_seed(0)
-    model = O.OracleGraphSAGE(7, hidden, out_dim, 2, 0.3).train()
+    if inference:
+        model = O.OracleGraphSAGE(7, hidden, out_dim, layers, 0.0).eval()
+        with torch.no_grad():
+            model(x, ei)                                             # warm-up
+            steps, t0 = 0, time.perf_counter()
+            while steps < args.cpu_steps:
+                model(x, ei)
+                steps += 1
+                if time.perf_counter() - t0 > 20.0:
+                    break
+        dt = (time.perf_counter() - t0) / steps
+        return {"value": n / dt, "unit": "nodes/s", "cores": threads, "kind": "port",
+                "sample": f"{n}-node/{ei.size(1)}-edge graph from the same generator "
+                          f"(1/{max(nodes_full // n, 1)} of the workload), same model, {steps} "
+                          f"forwards, {dt * 1e3:.1f} ms each"}
+    b = max(1024, int(args.pairs_per_gpu * n / nodes_full))
+    model = O.OracleGraphSAGE(7, hidden, out_dim, layers, 0.3).train()
     opt = O.make_adam(model)
     batches = [cooccurrence_batch(ei, n, b, K, seed=s) for s in range(2)]
     O.train_step(model, opt, x, ei, *batches[0])                 # warm-up
@@ -84,58 +273,49 @@ def cpu_baseline(args, hidden, out_dim, K):
     dt = (time.perf_counter() - t0) / steps
     return {
         "value": b / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-        "sample": f"{n}-node/{ei.size(1)}-edge graph from the same generator (1/{nodes_full // n} "
+        "sample": f"{n}-node/{ei.size(1)}-edge graph from the same generator (1/{max(nodes_full // n, 1)} "
                   f"of the workload), {b} pairs/step (same pairs per node), {steps} steps, "
                   f"{dt * 1e3:.1f} ms/step",
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c4")
-    ap.add_argument("--pairs-per-gpu", type=int, default=1 << 20)
-    ap.add_argument("--negatives", type=int, default=5)
-    ap.add_argument("--dropout", type=float, default=0.3)
-    ap.add_argument("--cpu-nodes", type=int, default=200_000)
-    ap.add_argument("--cpu-steps", type=int, default=30)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--receptive-field", action="store_true",
-                    help="opt-in extra (not the headline): compute only the 2-hop closure of each "
-                         "batch (pays for small batches on large graphs)")
-    ap.add_argument("--cache-input-aggregation", action="store_true",
-                    help="opt-in extra (not the headline): keep mean_j x_j of the constant input "
-                         "features across steps instead of recomputing it like the reference")
-    args = ap.parse_args()
+# ------------------------------------------------------------------- launch-path self-test
+def run_selftest(args, R):
+    """GSAGE_BENCH_DIST_SELFTEST=1 (tests/test_bench_launch_cpu.py): the rank set-up, barrier,
+    max-over-ranks timing and result line of the real bench with the GPU work left out, so the
+    spawn / relay / exit-code logic can run on a CPU-only machine over gloo."""
+    fail = os.environ.get("GSAGE_BENCH_SELFTEST_FAIL_RANK")
+    if fail is not None and int(fail) == R.rank:
+        print(f"[bench r{R.rank}] self-test: failing on purpose", file=sys.stderr, flush=True)
+        sys.exit(7)
+    R.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + R.rank))
+    R.sync_all()
+    elapsed = R.max_over_ranks(time.perf_counter() - t0)
+    seen = R.count_ranks()
+    if R.rank == 0:
+        if os.environ.get("GSAGE_BENCH_SELFTEST_NOISE") == "1":
+            print("not the result line")
+        print(json.dumps({"metric": "launch self-test (no GPU work)", "value": 0.0, "unit": "none",
+                          "n_gpus": R.world, "ranks_seen": seen, "backend": R.backend,
+                          "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "selftest": True}),
+              flush=True)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal switch for a one-GPU box: all ranks on cuda:0 over gloo (RCCL needs one GPU per rank)
-    rehearse = os.environ.get("GSAGE_BENCH_REHEARSE_ONE_GPU") == "1"
-    if rehearse:
-        import faulthandler
-        faulthandler.dump_traceback_later(80, exit=True)
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device(f"cuda:{local_rank}"))
-    if args.gpus != world:
-        log(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
 
+# ------------------------------------------------------------------------------- training
+def run_training(args, R):
+    torch = R.torch
     from graphsage_amd import GraphSAGE, TrainStep, default_cache, ops
     from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
 
-    nodes, deg, hidden, out_dim, desc = WORKLOADS[args.workload]
+    nodes, deg, hidden, out_dim, layers, desc = WORKLOADS[args.workload]
+    if args.nodes:
+        nodes, desc = args.nodes, desc + f" [node count overridden: {args.nodes}]"
     K, B = args.negatives, args.pairs_per_gpu
+    dev, rank, world = R.dev, R.rank, R.world
 
     t0 = time.perf_counter()
     ei = powerlaw_graph(nodes, deg, seed=42, device=dev)       # same seed -> identical replicas
@@ -150,47 +330,26 @@ def main():
         f"hub rows {graph.n_long.tolist()}, max in-degree {int(graph.in_degree().max())}")
 
     torch.manual_seed(0)
-    model = GraphSAGE(7, hidden, out_dim, 2, args.dropout,
+    model = GraphSAGE(7, hidden, out_dim, layers, args.dropout,
                       cache_input_aggregation=args.cache_input_aggregation).to(dev)
     step = TrainStep(model, x, ei, receptive_field=args.receptive_field)
     nbatch = 4
     batches = [cooccurrence_batch(ei, nodes, B, K, seed=1000 * (rank + 1) + i) for i in range(nbatch)]
     torch.cuda.synchronize()
-    if rehearse:
-        print(f"[bench r{rank}] batches ready", file=sys.stderr, flush=True)
-
-    coll_dev = torch.device("cpu") if rehearse else dev      # gloo rehearsal: host tensors
-    token = torch.zeros(1, device=coll_dev)
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:                      # barrier = a one-element all-reduce
-            dist.all_reduce(token)
-            torch.cuda.synchronize()
-        if rehearse:
-            print(f"[bench r{rank}] barrier passed", file=sys.stderr, flush=True)
 
     for i in range(args.warmup):
         step.step(*batches[i % nbatch], global_batch=B * world)
-        if rehearse:
-            torch.cuda.synchronize()
-            print(f"[bench r{rank}] warmup step {i} done", file=sys.stderr, flush=True)
     timer = ops.KernelTimer()
     ops.set_kernel_timer(timer)
-    sync_all()
+    R.sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
         stats = step.step(*batches[i % nbatch], global_batch=B * world)
-        if rehearse:
-            print(f"[bench r{rank}] timed step {i} queued", file=sys.stderr, flush=True)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    R.sync_all()
+    elapsed = R.max_over_ranks(time.perf_counter() - t0)
     ops.set_kernel_timer(None)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     loss = float(stats[0].item())
+    seen = R.count_ranks()
 
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
@@ -204,15 +363,24 @@ def main():
     skip_launches, skip_ms = timer.summary().get(f"segment_gather_F{F}_skip", (0, float("nan")))
     alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if launches else float("nan")
-    traffic, traffic_src = measured_traffic(args.workload, F)
-    roofline = {"bound": "hbm", "kernel": f"seg_gather_vec_k<{F // 4},0,false> (hub rows included), F={F}",
+    kname = f"seg_gather_vec_k<{F // 4}, 0, false>"
+    traffic, traffic_src, stale = measured_traffic(args.workload, kname) if not args.nodes \
+        else (None, None, None)
+    roofline = {"bound": "hbm", "kernel": f"{kname} (hub rows included), F={F}",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_stale": stale, "csrc_hash": csrc_hash(),
                 "launches_timed": launches, "mean_ms": mean_ms, "algorithmic_bytes": alg_bytes}
     if skip_launches:
         roofline["masked_backward_gather"] = {
             "kernel": f"seg_gather_vec_k<{F // 4},0,masked>: rows whose gradient is zero are not fetched",
             "launches_timed": skip_launches, "mean_ms": skip_ms}
+
+    # the batch the reference would actually train with (config/config.yaml:37, trainer.py:108):
+    # a short second timed loop on the same graph, model and harness, eager
+    ref_batch = None
+    if world == 1 and not args.no_reference_batch:
+        ref_batch = reference_batch_leg(args, R, step, ei, nodes, K)
 
     # fp32 storage and accumulation everywhere; the 128/256-wide GEMMs (C3) feed the bf16 matrix
     # pipe with each fp32 operand split exactly into three bf16 parts (fp32-equivalent results)
@@ -222,10 +390,11 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on the bounded sample ...")
-            cpu = cpu_baseline(args, hidden, out_dim, K)
+            cpu = cpu_baseline(args, hidden, out_dim, layers, K)
         print(json.dumps({
             "metric": "co-occurrence pairs/sec trained (fwd+bwd+step)", "value": value,
-            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "pairs/s", "n_gpus": world, "ranks_seen": seen, "backend": R.backend,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": desc, "nodes": nodes, "edges": E, "negatives": K,
@@ -240,10 +409,147 @@ def main():
                        "loss_backward": "deterministic (sorted)" if ops.loss_bwd_deterministic(nodes, B, K)
                        else "atomic",
                        "final_loss": loss},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "reference_batch": ref_batch, "cpu_baseline": cpu,
         }), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+
+
+def reference_batch_leg(args, R, step, ei, nodes, K, pairs=1024, steps=10, warmup=2):
+    torch = R.torch
+    from graphsage_amd.synth import cooccurrence_batch
+    batches = [cooccurrence_batch(ei, nodes, pairs, K, seed=77 + i) for i in range(2)]
+
+    def timed(n_warm, n_steps):
+        for i in range(n_warm):
+            step.step(*batches[i % 2], global_batch=pairs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step.step(*batches[i % 2], global_batch=pairs)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n_steps
+
+    was = step.receptive_field
+    step.receptive_field = False
+    dt = timed(warmup, steps)
+    out = {"pairs": pairs, "ms_per_step": dt * 1e3, "pairs_per_s": pairs / dt, "steps": steps,
+           "graph_pass": "full graph every step (as the reference), eager",
+           "source": "config/config.yaml:37 batch_size=1024"}
+    # the same batch through the opt-in 2-hop-closure step (same parameters afterwards): labelled
+    step.receptive_field = True
+    dt_rf = timed(warmup, steps)
+    out["receptive_field_opt_in"] = {"ms_per_step": dt_rf * 1e3, "pairs_per_s": pairs / dt_rf,
+                                     "graph_pass": "2-hop closure of the batch only (opt-in)"}
+    step.receptive_field = was
+    return out
+
+
+# ------------------------------------------------------------------------------ inference
+def run_inference(args, R):
+    """C5: the device part of StructuralEncoder.encode_all (encoder.py:181-185) timed as
+    scripts/benchmark_latency.py:66-105 does: synchronise, K forwards one by one, synchronise."""
+    torch = R.torch
+    from graphsage_amd import GraphSAGE, default_cache, ops
+    from graphsage_amd.encoder import StructuralEncoder
+    from graphsage_amd.synth import memory_features, powerlaw_graph
+
+    nodes, deg, hidden, out_dim, layers, desc = WORKLOADS[args.workload]
+    if args.nodes:
+        nodes, desc = args.nodes, desc + f" [node count overridden: {args.nodes}]"
+    dev, rank, world = R.dev, R.rank, R.world
+    t0 = time.perf_counter()
+    ei = powerlaw_graph(nodes, deg, seed=42, device=dev)
+    x = memory_features(nodes, seed=42, device=dev)
+    E = ei.size(1)
+    graph = default_cache().get(ei, nodes)
+    torch.cuda.synchronize()
+    log(f"graph: N={nodes} E={E} generated + CSR in {time.perf_counter() - t0:.1f}s")
+    torch.manual_seed(0)
+    enc = StructuralEncoder(model=GraphSAGE(7, hidden, out_dim, layers, 0.0), device=str(dev))
+    for _ in range(args.warmup):
+        emb = enc.encode_tensors(x, ei)
+    del graph
+    timer = ops.KernelTimer()
+    ops.set_kernel_timer(timer)
+    R.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        emb = enc.encode_tensors(x, ei)
+    R.sync_all()
+    elapsed = R.max_over_ranks(time.perf_counter() - t0)
+    ops.set_kernel_timer(None)
+    seen = R.count_ranks()
+    norms = emb.norm(dim=1)
+    unit = bool(((norms - 1).abs() < 1e-4).all().item())
+    ms = elapsed / args.steps * 1e3
+    summ = timer.summary()
+
+    # the MFMA-bound kernel: the 256 -> 256 projections (layers 2 and 3), gemm_split_k<4>:
+    # [agg|x] (N x 512) . [W_l|W_r]^T (512 x 256) on the bf16 matrix pipe, each fp32 product
+    # as six exact bf16 products (DESIGN 3)
+    split = os.environ.get("GSAGE_WIDE_GEMM", "")[:1] != "f"
+    launches, mean_ms = summ.get(f"project_fwd_{hidden}x{out_dim}", (0, float("nan")))
+    f32_flops = 2.0 * nodes * (2 * hidden) * out_dim
+    issued = f32_flops * (6.0 if split else 1.0)
+    peak = MFMA_BF16_PEAK_TFS if split else MFMA_F32_PEAK_TFS
+    ach = issued / (mean_ms * 1e-3) / 1e12 if launches else float("nan")
+    roofline = {
+        "bound": "mfma",
+        "kernel": ("gemm_split_k<4>" if split else "gemm_wide_k<2>") +
+                  f" ({hidden}->{out_dim} projection; the bracket also holds the weight pack/split, "
+                  "microseconds)",
+        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        "flops_counted": "MFMA flops issued = 6 bf16 products per fp32 product" if split
+        else "fp32 MFMA flops",
+        "fp32_equivalent_tflops": f32_flops / (mean_ms * 1e-3) / 1e12 if launches else None,
+        "fp32_equivalent_frac_of_f32_matrix_peak":
+            f32_flops / (mean_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS if launches else None,
+        "traffic": None, "launches_timed": launches, "mean_ms": mean_ms,
+        "algorithmic_flops": f32_flops, "csrc_hash": csrc_hash()}
+    F = hidden
+    gl, gms = summ.get(f"segment_gather_F{F}", (0, float("nan")))
+    alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F
+    gach = alg_bytes / (gms * 1e-3) / 1e9 if gl else float("nan")
+    roofline["gather"] = {"bound": "hbm", "kernel": f"seg_gather_vec_k<{F // 4}, 0, false>, F={F}",
+                          "achieved": gach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": gach / HBM_PEAK_GBS, "launches_timed": gl, "mean_ms": gms,
+                          "algorithmic_bytes": alg_bytes}
+    per_kernel = {k: {"launches": v[0], "mean_ms": v[1]} for k, v in sorted(summ.items())}
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle forward on the bounded sample ...")
+            cpu = cpu_baseline(args, hidden, out_dim, layers, 0, inference=True)
+        print(json.dumps({
+            "metric": "full-graph inference encode, nodes/sec (BASELINE config 5)",
+            "value": nodes * world * args.steps / elapsed, "unit": "nodes/s", "n_gpus": world,
+            "ranks_seen": seen, "backend": R.backend, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 (wide GEMMs: bf16 MFMA on 3-way split fp32 operands, fp32 accumulate)"
+            if split else "f32", "data": "synthetic",
+            "config": {"workload": desc, "nodes": nodes, "edges": E,
+                       "model": f"7->{hidden}->{hidden}->{out_dim}, eval, no_grad, L2-normalised",
+                       "parallelism": "replicas only (inference does not shard)" if world > 1
+                       else "single GPU", "unit_norm_rows": unit,
+                       "protocol": "scripts/benchmark_latency.py:66-105"},
+            "roofline": roofline, "kernels_ms": per_kernel, "cpu_baseline": cpu,
+        }), flush=True)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))       # before any GPU call in this process
+    R = Ranks(args)
+    if SELFTEST:
+        run_selftest(args, R)
+    elif args.workload == "c5":
+        run_inference(args, R)
+    else:
+        run_training(args, R)
+    R.finish()
 
 
 if __name__ == "__main__":

@@ -138,11 +138,16 @@ def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0
         if want_relu_sign and alloc_relu_sign and Fi <= 8 and Fo % 64 == 0 and epilogue in (_lib.EPI_RELU,
                                                                        _lib.EPI_RELU_DROPOUT):
             sign = torch.empty(lib.gsage_relu_sign_bytes(N, Fo) // 8, dtype=torch.int64, device=dev)
+        ev = _timer.bracket(f"project_fwd_{Fi}x{Fo}") if _timer is not None and _timer.enabled else None
+        if ev:
+            ev[0].record()
         rc = lib.gsage_project_fwd_ex(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), b_l.data_ptr(),
                                       w_r.data_ptr(), N, Fi, Fo, int(epilogue), _lib.ptr(keep_mask),
                                       int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), out.data_ptr(),
                                       _lib.ptr(rnorm), wpack.data_ptr(), int(force_generic),
                                       _lib.ptr(sign), _lib.stream_handle())
+        if ev:
+            ev[1].record()
     _lib.check(rc, "gsage_project_fwd")
     if want_relu_sign:
         return out, rnorm, sign
