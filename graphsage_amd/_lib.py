@@ -49,6 +49,9 @@ SIGNATURES = {
     "gsage_skipgram_workspace_bytes": (_sz, [_i64]),
     "gsage_skipgram_fwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, C.c_float,
                                      C.c_double, C.c_double, _p, _p, _p, _sz, _p]),
+    "gsage_skipgram_noalloc_max_pairs": (_i64, []),
+    "gsage_skipgram_fwd_noalloc": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, C.c_float,
+                                             C.c_double, C.c_double, _p, _p, _p]),
     "gsage_skipgram_bwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "gsage_alias_build_host": (C.c_int, [_p, _i64, _p, _p]),
     "gsage_random_walks": (C.c_int, [_p, _p, _i64, _i64, _i64, C.c_uint64, _p, _p, _p]),
@@ -92,7 +95,7 @@ def load() -> C.CDLL:
 def check(status: int, what: str) -> None:
     if status != 0:
         msg = load().gsage_error_string(status).decode()
-        exc = ValueError if status in (-1, -2) else RuntimeError
+        exc = ValueError if status in (-1, -2, -5) else RuntimeError
         raise exc(f"{what}: {msg} (gsage status {status})")
 
 

@@ -10,6 +10,7 @@ extern "C" const char *gsage_error_string(int status) {
     case GSAGE_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
     case GSAGE_ERR_WORKSPACE: return "workspace too small";
     case GSAGE_ERR_LAUNCH: return "HIP launch failed";
+    case GSAGE_ERR_TOO_LARGE: return "size beyond the fixed scratch of a no-alloc entry point";
     default: return "unknown gsage status";
   }
 }

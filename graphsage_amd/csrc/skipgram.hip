@@ -14,6 +14,8 @@
 #include "gsage_common.h"
 #include "gsage_sort.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int SG_MAX_BLOCKS = 2048;
@@ -330,7 +332,7 @@ int sg_blocks(int64_t B, int pairs_per_block) {
 
 extern "C" size_t gsage_skipgram_workspace_bytes(int64_t B) {
   (void)B;
-  return (size_t)SG_MAX_BLOCKS * 8 * sizeof(float) + 256;
+  return (size_t)SG_MAX_BLOCKS * 8 * sizeof(float);
 }
 
 extern "C" int gsage_skipgram_fwd(const float *emb, int64_t N, int64_t D, const int64_t *targets,
@@ -369,6 +371,53 @@ extern "C" int gsage_skipgram_fwd(const float *emb, int64_t N, int64_t D, const 
                      stats);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
+}
+
+// ------------------------------------------------- K4 for callers that cannot allocate
+// The per-workgroup partials of the loss forward live in a file-scope device array instead of a
+// caller's workspace.  `scratch` below is a HOST-side stand-in for the symbol: its device
+// address is looked up once per device with hipGetSymbolAddress (each GPU holds its own copy of
+// the array at its own address) and only that pointer is ever handed to a kernel.
+static __device__ __align__(256) float scratch[SG_MAX_BLOCKS * 8];   // 64 KiB per GPU
+
+namespace {
+constexpr int SG_MAX_DEVICES = 64;
+std::mutex sg_scratch_mu;
+float *sg_scratch_ptr[SG_MAX_DEVICES];   // per device; nullptr = not looked up yet
+
+// device address of `scratch` on the CURRENT device (looked up on the first call there)
+int sg_scratch_for_current_device(float **out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SG_MAX_DEVICES) return GSAGE_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lock(sg_scratch_mu);
+  if (!sg_scratch_ptr[dev]) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      return GSAGE_ERR_LAUNCH;
+    }
+    sg_scratch_ptr[dev] = (float *)p;
+  }
+  *out = sg_scratch_ptr[dev];
+  return GSAGE_OK;
+}
+}  // namespace
+
+extern "C" int64_t gsage_skipgram_noalloc_max_pairs(void) { return GSAGE_SKIPGRAM_NOALLOC_MAX_PAIRS; }
+
+extern "C" int gsage_skipgram_fwd_noalloc(const float *emb, int64_t N, int64_t D,
+                                          const int64_t *targets, const int64_t *contexts,
+                                          const int64_t *negatives, int64_t B, int64_t K,
+                                          float scale, double loss_norm_B, double loss_norm_BK,
+                                          float *coef, float *stats, gsage_stream_t stream) {
+  if (B > GSAGE_SKIPGRAM_NOALLOC_MAX_PAIRS) return GSAGE_ERR_TOO_LARGE;
+  float *ptr = nullptr;
+  int rc = sg_scratch_for_current_device(&ptr);
+  if (rc) return rc;
+  // every workgroup overwrites its whole partial row and the finishing kernel reads only the
+  // rows of this launch's grid, so nothing of the previous call's contents has to be cleared
+  return gsage_skipgram_fwd(emb, N, D, targets, contexts, negatives, B, K, scale, loss_norm_B,
+                            loss_norm_BK, coef, stats, ptr, sizeof(scratch), stream);
 }
 
 extern "C" int gsage_skipgram_bwd(const float *emb, int64_t N, int64_t D, const int64_t *targets,

@@ -34,7 +34,8 @@ enum gsage_status {
   GSAGE_ERR_INVALID_ARG = -1,   /* null pointer, negative size, bad enum        */
   GSAGE_ERR_UNSUPPORTED = -2,   /* shape outside what the kernel handles        */
   GSAGE_ERR_WORKSPACE = -3,     /* workspace too small                          */
-  GSAGE_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after launch */
+  GSAGE_ERR_LAUNCH = -4,        /* hipGetLastError() != hipSuccess after launch */
+  GSAGE_ERR_TOO_LARGE = -5      /* size beyond the fixed scratch of a *_noalloc entry point */
 };
 
 /* bits OR-ed into device status words */
@@ -214,6 +215,26 @@ int gsage_skipgram_bwd(const float *emb, int64_t N, int64_t D, const int64_t *ta
                        const int64_t *contexts, const int64_t *negatives, int64_t B,
                        int64_t K, const float *coef, const float *grad_loss,
                        float *grad_emb, gsage_stream_t stream);
+
+/* K4 for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers
+ * that must not (or cannot) call hipMalloc or bring a workspace -- code under HIP graph capture,
+ * tight serving loops that evaluate the loss, harnesses that forbid allocation.  Same arguments,
+ * results and kernels as gsage_skipgram_fwd, minus `ws`: the per-workgroup partial sums live in a
+ * 64 KiB file-scope device array of the library (one copy per GPU, held until the process ends),
+ * whose address is looked up on the first call on each device (so make that first call outside a
+ * graph capture).  The call makes no hipMalloc / hipFree and calls no allocating routine.
+ *   limit : B <= gsage_skipgram_noalloc_max_pairs() (GSAGE_SKIPGRAM_NOALLOC_MAX_PAIRS = 2^24);
+ *           larger B returns GSAGE_ERR_TOO_LARGE and launches nothing.
+ *   All calls on one GPU share that GPU's array: calls that may OVERLAP on one GPU (different
+ *   streams, different host threads) race on it -- serialise them or use gsage_skipgram_fwd with
+ *   a workspace each.  Calls in stream order are safe: each launch rewrites every partial it
+ *   later reads, so nothing has to be cleared between calls. */
+#define GSAGE_SKIPGRAM_NOALLOC_MAX_PAIRS ((int64_t)1 << 24)
+int64_t gsage_skipgram_noalloc_max_pairs(void);
+int gsage_skipgram_fwd_noalloc(const float *emb, int64_t N, int64_t D, const int64_t *targets,
+                               const int64_t *contexts, const int64_t *negatives, int64_t B,
+                               int64_t K, float scale, double loss_norm_B, double loss_norm_BK,
+                               float *coef, float *stats, gsage_stream_t stream);
 
 /* K5, deterministic form: the same gradient as gsage_skipgram_bwd without atomics.  The
  * 2(1+K) terms of every pair are stably sorted by destination row (K1's radix sort) into a
