@@ -54,6 +54,7 @@ SIGNATURES = {
                                              C.c_double, C.c_double, _p, _p, _p]),
     "gsage_skipgram_bwd": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "gsage_alias_build_host": (C.c_int, [_p, _i64, _p, _p]),
+    "gsage_alias_sample": (C.c_int, [_p, _p, _i64, _i64, C.c_uint64, C.c_uint64, _p, _p]),
     "gsage_random_walks": (C.c_int, [_p, _p, _i64, _i64, _i64, C.c_uint64, _p, _p, _p]),
     "gsage_walk_pair_counts": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "gsage_walk_pairs_gather": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _p, _p]),

@@ -97,7 +97,50 @@ walk_pairs_gather_k(const int *__restrict__ walks, const int *__restrict__ lengt
   }
 }
 
+// ---- negatives by the alias method (DegreeBiasedNegativeSampler.sample,
+// src/walks/negative_sampler.py:147-178: a uniform bin, a uniform threshold, `alias[bin]` where
+// threshold >= prob_table[bin], else the bin).  One thread per draw; the random stream is a
+// counter hash of (seed, draw number) -- three murmur3-finalised words: 64 bits pick the bin
+// (bias N / 2^64), 24 bits make the threshold.  Mirrored on the host in graphsage_amd/rng.py.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+__global__ void __launch_bounds__(256)
+alias_sample_k(const float *__restrict__ prob_table, const int64_t *__restrict__ alias, int64_t N,
+               int64_t count, uint64_t seed, uint64_t first_draw, int64_t *__restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += stride) {
+    const uint64_t ctr = first_draw + (uint64_t)q;
+    const uint32_t lo = (uint32_t)ctr, hi = (uint32_t)(ctr >> 32);
+    const uint32_t a = fmix32(((uint32_t)seed ^ (lo * 0x9E3779B1u)) ^
+                              ((uint32_t)(seed >> 32) + hi * 0x85EBCA77u));
+    const uint32_t b = fmix32(a ^ 0x68E31DA4u ^ (lo * 0xB5297A4Du));
+    const uint32_t c = fmix32((b + 0x1B56C4E9u + (uint32_t)(seed >> 32)) ^ hi);
+    // bin = floor(x * N / 2^64), x = a:c, without a 128-bit product (N < 2^31)
+    const uint64_t n = (uint64_t)N;
+    const int64_t bin = (int64_t)(((uint64_t)a * n + (((uint64_t)c * n) >> 32)) >> 32);
+    const float u = (float)(b >> 8) * (1.0f / 16777216.0f);
+    out[q] = u >= prob_table[bin] ? alias[bin] : bin;
+  }
+}
+
 }  // namespace
+
+extern "C" int gsage_alias_sample(const float *prob_table, const int64_t *alias, int64_t N,
+                                  int64_t count, uint64_t seed, uint64_t first_draw,
+                                  int64_t *out, gsage_stream_t stream) {
+  if (N <= 0 || count < 0 || !prob_table || !alias || !out) return GSAGE_ERR_INVALID_ARG;
+  if (N >= (1ll << 31)) return GSAGE_ERR_UNSUPPORTED;
+  if (count == 0) return GSAGE_OK;
+  hipLaunchKernelGGL(alias_sample_k, dim3(gs_grid(count, 256 * 4, 256 * 32)), dim3(256), 0,
+                     gs_stream(stream), prob_table, alias, N, count, seed, first_draw, out);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}
 
 extern "C" int gsage_random_walks(const int32_t *rowptr_t, const int32_t *col_t, int64_t N,
                                   int64_t walk_length, int64_t walks_per_node, uint64_t seed,

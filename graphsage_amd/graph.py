@@ -7,6 +7,7 @@ K1 kernels (``gsage_csr_build``) and reused by every layer, forward and backward
 from __future__ import annotations
 
 import weakref
+from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -82,43 +83,65 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int, check: bool = True) -> G
 class GraphCache:
     """Keeps the CSR of the graphs recently seen, keyed on the identity of the ``edge_index``
     tensor OBJECT (held weakly) and its in-place version counter.  A device pointer alone is
-    not an identity: the caching allocator hands the same address to the next graph."""
+    not an identity: the caching allocator hands the same address to the next graph.
 
-    def __init__(self, capacity: int = 4):
+    Three separate stores, so that one kind of entry never evicts another: CSRs (``capacity``
+    entries, least recently USED goes first), padded input features, cached input aggregates
+    (``aux_capacity`` each).  Entries whose key tensor has died are swept on every insert."""
+
+    def __init__(self, capacity: int = 4, aux_capacity: int = 4):
         self.capacity = capacity
-        self._store: Dict[object, Tuple] = {}
+        self.aux_capacity = aux_capacity
+        self._graphs: "OrderedDict[int, Tuple]" = OrderedDict()
+        self._pads: "OrderedDict[Tuple, Tuple]" = OrderedDict()
+        self._aggs: "OrderedDict[Tuple, Tuple]" = OrderedDict()
+        self.builds = 0                 # CSR builds so far (tests, diagnostics)
+
+    @staticmethod
+    def _sweep(store) -> None:
+        for dead in [k for k, e in store.items() if any(r() is None for r in e[0])]:
+            del store[dead]
+
+    @staticmethod
+    def _insert(store, key, entry, capacity: int) -> None:
+        GraphCache._sweep(store)
+        while len(store) >= capacity:
+            store.popitem(last=False)
+        store[key] = entry
 
     def get(self, edge_index: torch.Tensor, num_nodes: int) -> GraphCSR:
         k = id(edge_index)
-        ent = self._store.get(k)
+        ent = self._graphs.get(k)
         if ent is not None:
-            ref, version, n, g = ent
+            (ref,), version, n, g = ent
             if ref() is edge_index and version == edge_index._version and n == int(num_nodes):
+                self._graphs.move_to_end(k)
                 return g
-            del self._store[k]
-        for dead in [kk for kk, e in self._store.items() if e[0]() is None]:
-            del self._store[dead]
+            del self._graphs[k]
         g = build_csr(edge_index, num_nodes)
-        if len(self._store) >= self.capacity:
-            self._store.pop(next(iter(self._store)))
-        self._store[k] = (weakref.ref(edge_index), edge_index._version, int(num_nodes), g)
+        self.builds += 1
+        self._insert(self._graphs, k, ((weakref.ref(edge_index),), edge_index._version,
+                                       int(num_nodes), g), self.capacity)
         return g
 
-    def padded(self, x: torch.Tensor, width: int) -> torch.Tensor:
-        """``x`` zero-padded to ``width`` columns.  Cached per tensor object + version when x
-        needs no gradient (node features are constant across training steps)."""
+    def padded(self, x: torch.Tensor, width: int, keep: bool = True) -> torch.Tensor:
+        """``x`` zero-padded to ``width`` columns.  With ``keep`` the result is cached per tensor
+        object + version when x needs no gradient: for the INPUT features, which are constant
+        across training steps.  Callers padding a temporary (a hidden activation in eval mode)
+        pass ``keep=False``: such a tensor never comes back, caching it would only hold memory."""
         pad = width - x.size(1)
-        if x.requires_grad:
+        if x.requires_grad or not keep:
             return torch.nn.functional.pad(x, (0, pad))
-        k = ("pad", id(x), width)
-        ent = self._store.get(k)
+        k = (id(x), width)
+        ent = self._pads.get(k)
         if ent is not None:
-            ref, version, xp = ent
+            (ref,), version, xp = ent
             if ref() is x and version == x._version:
+                self._pads.move_to_end(k)
                 return xp
-            del self._store[k]
+            del self._pads[k]
         xp = torch.nn.functional.pad(x, (0, pad)).contiguous()
-        self._store[k] = (weakref.ref(x), x._version, xp)
+        self._insert(self._pads, k, ((weakref.ref(x),), x._version, xp), self.aux_capacity)
         return xp
 
     def aggregated(self, x_key: torch.Tensor, x: torch.Tensor, graph: "GraphCSR", compute):
@@ -127,19 +150,42 @@ class GraphCache:
         training steps, so an opt-in caller (``GraphSAGE(cache_input_aggregation=True)``) can skip
         the first layer's gather after the first step.  ``x_key`` is the caller's tensor, ``x``
         the (possibly padded) one that is aggregated."""
-        k = ("agg", id(x_key), id(graph))
-        ent = self._store.get(k)
+        k = (id(x_key), id(graph))
+        ent = self._aggs.get(k)
         if ent is not None:
-            ref, version, gref, agg = ent
+            (ref, gref), version, agg = ent
             if ref() is x_key and version == x_key._version and gref() is graph:
+                self._aggs.move_to_end(k)
                 return agg
-            del self._store[k]
+            del self._aggs[k]
         agg = compute(graph, x)
-        self._store[k] = (weakref.ref(x_key), x_key._version, weakref.ref(graph), agg)
+        self._insert(self._aggs, k, ((weakref.ref(x_key), weakref.ref(graph)), x_key._version, agg),
+                     self.aux_capacity)
         return agg
 
+    def held_for(self, features: torch.Tensor, edge_index: torch.Tensor) -> list:
+        """Strong references to everything cached for this (features, edge_index) pair: the CSR,
+        the padded features, the cached aggregate.  A captured HIP graph has their device
+        addresses baked in, so whoever owns that graph must keep these alive itself rather than
+        rely on this cache not evicting them (TrainStep.capture_step does)."""
+        out = []
+        g = None
+        ent = self._graphs.get(id(edge_index))
+        if ent is not None and ent[0][0]() is edge_index:
+            g = ent[3]
+            out.append(g)
+        for (refs, _, val) in self._pads.values():
+            if refs[0]() is features:
+                out.append(val)
+        for (refs, _, val) in self._aggs.values():
+            if refs[0]() is features and (g is None or refs[1]() is g):
+                out.append(val)
+        return out
+
     def clear(self) -> None:
-        self._store.clear()
+        self._graphs.clear()
+        self._pads.clear()
+        self._aggs.clear()
 
 
 _default_cache: Optional[GraphCache] = None

@@ -58,7 +58,9 @@ class SAGEConv(nn.Module):
 
     def run(self, x: torch.Tensor, graph: GraphCSR, epilogue: int = _lib.EPI_NONE, p: float = 0.0,
             seed: int = 0, keep_mask: Optional[torch.Tensor] = None,
-            force_generic: bool = False) -> torch.Tensor:
+            force_generic: bool = False, input_layer: bool = True) -> torch.Tensor:
+        """``input_layer``: x is the model's input (constant node features), so its padded copy is
+        worth caching; hidden activations are temporaries and are padded without caching."""
         w_l, w_r = self.lin_l.weight, self.lin_r.weight
         x_key = x
         width = vector_width(x.size(1))
@@ -66,10 +68,10 @@ class SAGEConv(nn.Module):
             # e.g. the 7 memory features -> 8 columns: 32-byte rows that the 16-byte-per-lane
             # gather (and its hub-row pass) can take; zero columns change no result
             pad = width - x.size(1)
-            x = default_cache().padded(x, width)
+            x = default_cache().padded(x, width, keep=input_layer)
             w_l, w_r = F.pad(w_l, (0, pad)), F.pad(w_r, (0, pad))
         agg = None
-        if self.cache_aggregation and not x_key.requires_grad:
+        if self.cache_aggregation and input_layer and not x_key.requires_grad:
             agg = default_cache().aggregated(x_key, x, graph, aggregate_mean)
         return SAGELayerFunction.apply(x, w_l, self.lin_l.bias, w_r, graph, epilogue, p, seed,
                                        keep_mask, force_generic, agg)
@@ -130,11 +132,14 @@ class GraphSAGE(nn.Module):
             if training:
                 km = keep_masks[i] if keep_masks is not None else None
                 seed = 0 if km is not None else self._dropout_seed()
-                x = conv.run(x, graph, _lib.EPI_RELU_DROPOUT, p, seed, km, self._force_generic)
+                x = conv.run(x, graph, _lib.EPI_RELU_DROPOUT, p, seed, km, self._force_generic,
+                             input_layer=i == 0)
             else:
-                x = conv.run(x, graph, _lib.EPI_RELU, 0.0, 0, None, self._force_generic)
+                x = conv.run(x, graph, _lib.EPI_RELU, 0.0, 0, None, self._force_generic,
+                             input_layer=i == 0)
         epi = _lib.EPI_L2NORM if self.normalize_output else _lib.EPI_NONE
-        return self.convs[-1].run(x, graph, epi, 0.0, 0, None, self._force_generic)
+        return self.convs[-1].run(x, graph, epi, 0.0, 0, None, self._force_generic,
+                                  input_layer=len(self.convs) == 1)
 
     def get_embedding_dim(self) -> int:
         return self.out_channels

@@ -36,6 +36,7 @@ class DegreeBiasedNegativeSampler:
         weights = degree ** exponent
         probs = weights / weights.sum()
         self.probs = probs.to(self.device)
+        self._seed, self._draws = None, 0
         self._setup_alias_table(probs)
 
     def _setup_alias_table(self, probs_cpu: torch.Tensor) -> None:
@@ -50,13 +51,39 @@ class DegreeBiasedNegativeSampler:
         self.prob_table = torch.from_numpy(prob_table).to(self.device)
 
     def sample(self, num_samples: int, num_negatives: int = 5) -> torch.Tensor:
-        """int64 [num_samples, num_negatives]; same draw sequence as the reference
-        (``negative_sampler.py:147-178``: randint bin, rand threshold, alias or bin)."""
+        """int64 [num_samples, num_negatives]; same draw rule as the reference
+        (``negative_sampler.py:147-178``: uniform bin, uniform threshold, alias or bin).
+
+        On a GPU the whole call is ONE kernel (``gsage_alias_sample``: a counter-hash stream
+        seeded once from torch's CPU generator, so ``torch.manual_seed`` reproduces a run) and the
+        library must be present.  A sampler left on the CPU -- the reference's default device --
+        draws with the reference's own three torch ops."""
         total = num_samples * num_negatives
+        if torch.device(self.device).type == "cuda":
+            return self._sample_device(total).view(num_samples, num_negatives)
         idx = torch.randint(0, self.num_nodes, (total,), device=self.device)
         u = torch.rand(total, device=self.device)
         samples = torch.where(u >= self.prob_table[idx], self.alias[idx], idx)
         return samples.view(num_samples, num_negatives)
+
+    def _sample_device(self, total: int) -> torch.Tensor:
+        lib = _lib.load()
+        if getattr(self, "_seed", None) is None:
+            self._seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            self._draws = 0
+        dev = self.prob_table.device
+        with torch.cuda.device(dev):
+            out = torch.empty(total, dtype=torch.int64, device=dev)
+            rc = lib.gsage_alias_sample(self.prob_table.data_ptr(), self.alias.data_ptr(),
+                                        self.num_nodes, total, self._seed & 0xFFFFFFFFFFFFFFFF,
+                                        self._draws, out.data_ptr(), _lib.stream_handle())
+        _lib.check(rc, "gsage_alias_sample")
+        self._draws += total
+        return out
+
+    def reseed(self, seed: int) -> None:
+        """Restart the device draw stream at counter 0 of ``seed`` (tests, reproducible runs)."""
+        self._seed, self._draws = int(seed), 0
 
     def get_probability(self, node_idx: int) -> float:
         return self.probs[node_idx].item()

@@ -74,6 +74,8 @@ class TrainStep:
                                           weight_decay=weight_decay, capturable=on_gpu,
                                           foreach=False if not on_gpu else None)
         self._graph = None
+        self._held: list = []            # what a captured graph's addresses point into
+        self._captured_versions = None
         # opt-in (graphsage_amd/receptive.py): compute only the 2-hop closure of the batch
         self.receptive_field = bool(receptive_field)
         self.distributed = dist.is_available() and dist.is_initialized()
@@ -154,6 +156,13 @@ class TrainStep:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._graph_body(batch_size)
+        # The captured kernels hold raw device addresses of tensors that only the process-wide
+        # GraphCache owns (the CSR built during warm-up, the 7 -> 8 padded features, a cached
+        # input aggregate).  Keep them alive here for as long as the graph exists, whatever the
+        # cache evicts later, and remember which versions of the inputs they were made from.
+        from .graph import default_cache
+        self._held = default_cache().held_for(self.features, self.edge_index)
+        self._captured_versions = (self.features._version, self.edge_index._version)
         if saved is not None:
             with torch.no_grad():
                 self.flat.flat.copy_(saved[0])
@@ -185,6 +194,12 @@ class TrainStep:
         """Replay the captured step on a new batch (copied into the graph's static inputs)."""
         if self._graph is None:
             raise RuntimeError("call capture_step() first")
+        if (self.features._version, self.edge_index._version) != self._captured_versions:
+            # an in-place change of the graph or the features: the captured kernels would go on
+            # reading the CSR / padded copy made from the old contents
+            self._graph, self._held = None, []
+            raise RuntimeError("features or edge_index were modified in place after capture_step(); "
+                               "capture again")
         self._gt.copy_(targets)
         self._gc.copy_(contexts)
         self._gn.copy_(negatives)

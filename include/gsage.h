@@ -283,6 +283,18 @@ int gsage_walk_pairs_gather(const int32_t *walks, const int32_t *lengths, int64_
 int gsage_alias_build_host(const float *scaled_probs, int64_t n, float *prob_table,
                            int64_t *alias);
 
+/* ------------------------------------------------ feeder: negatives by the alias method
+ * Replaces DegreeBiasedNegativeSampler.sample (src/walks/negative_sampler.py:147-178:
+ * `idx = randint(N)`, `u = rand()`, `where(u >= prob_table[idx], alias[idx], idx)`) and the
+ * per-batch call of it in BatchGenerator.__iter__ (src/training/batch_generator.py:181-187),
+ * as ONE launch in front of the loss kernel (which reads `out` as its `negatives`).
+ *   prob_table fp32 [N], alias int64 [N]: DEVICE copies of the table gsage_alias_build_host made;
+ *   out int64 [count] (count = B*K, row-major [B,K]); draw q uses counter first_draw + q of the
+ *   stream `seed` (a counter hash, not torch's Philox: draws agree in distribution, not value;
+ *   the host mirror graphsage_amd/rng.py reproduces them bit for bit). */
+int gsage_alias_sample(const float *prob_table, const int64_t *alias, int64_t N, int64_t count,
+                       uint64_t seed, uint64_t first_draw, int64_t *out, gsage_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

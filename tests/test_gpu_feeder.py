@@ -1,0 +1,123 @@
+"""GPU: the device-side feeder: alias tables resident on the GPU equal the tables
+the reference's own src/walks code produced (tests/golden/alias_golden.npz) bit for bit; the
+negatives come from ONE HIP kernel (gsage_alias_sample) whose draws equal the host mirror bit
+for bit and whose frequencies match `probs` (the reference's check, tests/test_walks.py:170-186);
+BatchGenerator epoch semantics (batch_generator.py:140-194) hold with everything on the device."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sage_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_alias_tables_bit_identical_to_reference(golden_dir):
+    from graphsage_amd import DegreeBiasedNegativeSampler
+    z = np.load(os.path.join(golden_dir, "alias_golden.npz"))
+    for g in ("g1", "g2", "g3"):
+        ei = torch.from_numpy(z[f"{g}.edge_index"]).cuda()
+        s = DegreeBiasedNegativeSampler(ei, int(z[f"{g}.num_nodes"]), exponent=0.75,
+                                        device=torch.device("cuda"))
+        assert s.probs.is_cuda and s.prob_table.is_cuda and s.alias.is_cuda
+        assert s.alias.dtype == torch.int64 and s.prob_table.dtype == torch.float32
+        assert np.array_equal(s.probs.cpu().numpy(), z[f"{g}.probs"]), g
+        assert np.array_equal(s.prob_table.cpu().numpy(), z[f"{g}.prob_table"]), g
+        assert np.array_equal(s.alias.cpu().numpy(), z[f"{g}.alias"]), g
+
+
+def test_kernel_draws_equal_host_mirror_and_oracle_rule():
+    from graphsage_amd import DegreeBiasedNegativeSampler, rng
+    from graphsage_amd.synth import powerlaw_graph
+    n = 50_000
+    ei = powerlaw_graph(n, 12, seed=3)
+    s = DegreeBiasedNegativeSampler(ei.cuda(), n, device=torch.device("cuda"))
+    _, prob_table, alias = O.alias_table(ei, n)               # oracle tables (= reference order)
+    assert torch.equal(s.prob_table.cpu(), prob_table) and torch.equal(s.alias.cpu(), alias)
+    s.reseed(0x1234ABCD5678)
+    a = s.sample(4096, 5)
+    b = s.sample(1000, 3)                                     # counters continue: 20480 ...
+    assert a.shape == (4096, 5) and a.dtype == torch.int64 and a.is_cuda
+    pt, al = prob_table.numpy(), alias.numpy()
+    want_a = rng.alias_sample(pt, al, 0x1234ABCD5678, 0, 4096 * 5).reshape(4096, 5)
+    want_b = rng.alias_sample(pt, al, 0x1234ABCD5678, 4096 * 5, 3000).reshape(1000, 3)
+    assert np.array_equal(a.cpu().numpy(), want_a) and np.array_equal(b.cpu().numpy(), want_b)
+    # the rule of negative_sampler.py:170-176 on the mirror's (bin, u): alias where u >= prob
+    bins, u = rng.alias_draws(0x1234ABCD5678, 0, 4096 * 5, n)
+    rule = torch.where(torch.from_numpy(u) >= prob_table[bins], alias[bins], torch.from_numpy(bins))
+    assert torch.equal(rule.view(4096, 5), a.cpu())
+    s.reseed(0x1234ABCD5678)
+    assert torch.equal(s.sample(4096, 5), a)                  # reproducible
+    # a counter beyond 2^32
+    s._draws = (1 << 33) + 5
+    c = s.sample(7, 5)
+    assert np.array_equal(c.cpu().numpy().ravel(), rng.alias_sample(pt, al, 0x1234ABCD5678, (1 << 33) + 5, 35))
+
+
+def test_sampler_shape_range_and_degree_bias_on_device():
+    """tests/test_walks.py:157-186 of the reference with the sampler on the GPU."""
+    from graphsage_amd import DegreeBiasedNegativeSampler
+    dev = torch.device("cuda")
+    ei = torch.tensor([[0, 0, 0, 1, 2, 3], [1, 2, 3, 0, 0, 0]]).cuda()
+    s = DegreeBiasedNegativeSampler(ei, 4, exponent=0.75, device=dev)
+    neg = s.sample(num_samples=10, num_negatives=5)
+    assert neg.shape == (10, 5) and neg.dtype == torch.int64 and neg.min() >= 0 and neg.max() < 4
+    ei2 = torch.tensor([[0, 0, 0, 0, 0, 1, 2], [1, 2, 3, 4, 5, 0, 0]]).cuda()
+    s2 = DegreeBiasedNegativeSampler(ei2, 6, device=dev)
+    torch.manual_seed(0)
+    draws = s2.sample(10000, 1).flatten()
+    counts = torch.bincount(draws, minlength=6).float() / 10000
+    assert counts[0] > 1.0 / 6                       # node 0 drawn more often than uniform
+    assert torch.allclose(counts, s2.probs, atol=0.02)
+    # and sharply: 4 M draws on a 2000-node power-law graph, chi-square against probs
+    from graphsage_amd.synth import powerlaw_graph
+    n = 2000
+    s3 = DegreeBiasedNegativeSampler(powerlaw_graph(n, 10, seed=1).cuda(), n, device=dev)
+    s3.reseed(99)
+    m = 4_000_000
+    cnt = torch.bincount(s3.sample(m, 1).flatten(), minlength=n).double().cpu()
+    exp = s3.probs.double().cpu() * m
+    big = exp >= 5                                   # isolated nodes (eps degree) are never drawn
+    chi2 = float(((cnt[big] - exp[big]) ** 2 / exp[big]).sum())
+    dof = int(big.sum()) - 1
+    assert chi2 < dof + 6 * (2 * dof) ** 0.5, (chi2, dof)
+    assert float(cnt[~big].sum()) <= 10 * float(exp[~big].sum()) + 10
+    # seeded from torch's CPU generator: manual_seed reproduces a fresh sampler's stream
+    torch.manual_seed(5)
+    x1 = DegreeBiasedNegativeSampler(ei2, 6, device=dev).sample(100, 5)
+    torch.manual_seed(5)
+    x2 = DegreeBiasedNegativeSampler(ei2, 6, device=dev).sample(100, 5)
+    assert torch.equal(x1, x2)
+
+
+def test_batch_generator_epoch_semantics_on_device():
+    """batch_generator.py:140-194 with pairs, permutation and negatives all on the GPU."""
+    from graphsage_amd import BatchGenerator, DegreeBiasedNegativeSampler
+    from graphsage_amd.synth import powerlaw_graph
+    dev = torch.device("cuda")
+    n = 500
+    s = DegreeBiasedNegativeSampler(powerlaw_graph(n, 8, seed=2).cuda(), n, device=dev)
+    tt = torch.arange(103)
+    gen = BatchGenerator((tt, tt + 1000), s, batch_size=32, num_negatives=5, device=dev)
+    assert len(gen) == 4
+    batches = list(gen)
+    assert [b.size for b in batches] == [32, 32, 32, 7]
+    t = torch.cat([b.targets for b in batches])
+    c = torch.cat([b.contexts for b in batches])
+    assert t.is_cuda and sorted(t.tolist()) == list(range(103)) and torch.equal(c, t + 1000)
+    for b in batches:
+        assert b.negatives.is_cuda and b.negatives.shape == (b.size, 5) and b.negatives.dtype == torch.int64
+        assert int(b.negatives.min()) >= 0 and int(b.negatives.max()) < n
+    assert not torch.equal(batches[0].negatives, batches[1].negatives)      # fresh per batch
+    t2 = torch.cat([b.targets for b in gen])
+    assert not torch.equal(t, t2)                                           # reshuffled per epoch
+    gen_d = BatchGenerator((tt, tt + 1000), s, 32, 5, device=dev, drop_last=True)
+    assert len(gen_d) == 3 and [b.size for b in gen_d] == [32, 32, 32]
+    # and the batches feed the loss kernel as they are
+    from graphsage_amd import SkipGramLoss
+    emb = torch.nn.functional.normalize(torch.randn(1200, 64, device=dev), dim=1)
+    b0 = batches[0]
+    loss, det = SkipGramLoss().forward_with_details(emb, b0.targets, b0.contexts, b0.negatives)
+    assert np.isfinite(det["total_loss"]) and det["total_loss"] > 0

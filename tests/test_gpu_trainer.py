@@ -199,3 +199,48 @@ def test_receptive_field_step_equals_full_graph_step(n, b, seed):
         assert_close(pb, pa, rtol=1e-4, floor=2e-5, what=name)
     with pytest.raises(IndexError):
         rf.step(t, c.clone().fill_(n), neg)
+
+
+def test_captured_step_survives_cache_churn_and_refuses_modified_inputs():
+    """The captured HIP graph has the addresses of the CSR / padded features baked in; they are
+    owned by the process-wide GraphCache, which other graphs and feature tensors may evict
+    (ADVICE r1, medium).  TrainStep holds them itself: after the cache has been churned and the
+    freed memory overwritten, replays still equal a run that was left alone."""
+    from graphsage_amd import TrainStep, default_cache
+    from graphsage_amd.synth import memory_features, powerlaw_graph
+    bs, k = 512, 5
+    g = torch.Generator().manual_seed(3)
+    results = []
+    for churn in (False, True):
+        n, ei, x, t, c, m, _ = _setup(seed=1)
+        negs = torch.randint(0, n, (6, bs, k), generator=torch.Generator().manual_seed(5)).cuda()
+        xg, eig = x.cuda(), ei.cuda()
+        default_cache().clear()
+        step = TrainStep(m, xg, eig)
+        step.capture_step(bs, k, preserve_state=True)
+        assert len(step._held) >= 2                         # CSR + padded features
+        for i in range(6):
+            if churn and i == 2:
+                builds = default_cache().builds
+                junk = []
+                for s in range(5):                          # five other graphs and feature tensors
+                    e2 = powerlaw_graph(900 + s, 6, seed=s).cuda()
+                    x2 = memory_features(900 + s, seed=s).cuda()
+                    default_cache().get(e2, 900 + s)
+                    default_cache().padded(x2, 8)
+                    junk.append((e2, x2))
+                assert default_cache().builds == builds + 5
+                torch.cuda.empty_cache()
+                filler = [torch.full((1 << 20,), 0x7FFFFFF0, dtype=torch.int32, device="cuda")
+                          for _ in range(16)]               # whatever was freed gets overwritten
+                del filler
+            lo = (i * bs) % (t.numel() - bs)
+            step.step_captured(t[lo:lo + bs].cuda(), c[lo:lo + bs].cuda(), negs[i])
+        torch.cuda.synchronize()
+        results.append([p.detach().clone() for p in m.parameters()])
+        if churn:
+            eig.add_(0)                                     # in-place change of the graph
+            with pytest.raises(RuntimeError, match="capture again"):
+                step.step_captured(t[:bs].cuda(), c[:bs].cuda(), negs[0])
+    for pa, pb in zip(*results):
+        assert_close(pa, pb, rtol=1e-5, floor=2e-6)

@@ -124,3 +124,53 @@ def test_stats_to_details_keys_and_index_error():
     assert d["total_loss"] == 3.0 and all(isinstance(v, float) for v in d.values())
     with pytest.raises(IndexError):
         stats_to_details(torch.tensor([0.0] * 7 + [1.0]))
+
+
+def test_graph_cache_keeps_the_live_csr_whatever_else_is_cached(monkeypatch):
+    """VERDICT r1 #10 / ADVICE: CSRs, padded features and cached aggregates have separate
+    stores; five other feature tensors (or aggregates) never evict the training graph; CSR
+    eviction is least-recently-USED; dead keys are swept on insert; temporaries are not kept."""
+    from graphsage_amd import graph as G
+    built = []
+
+    def fake_build(ei, n, check=True):
+        built.append(id(ei))
+        return G.GraphCSR(n, ei.size(1), *([torch.zeros(1)] * 9))
+
+    monkeypatch.setattr(G, "build_csr", fake_build)
+    cache = G.GraphCache(capacity=4)
+    ei = torch.zeros(2, 3, dtype=torch.int64)
+    g = cache.get(ei, 5)
+    feats = [torch.randn(5, 7) for _ in range(6)]
+    for f in feats:                                   # six feature tensors padded and aggregated
+        xp = cache.padded(f, 8)
+        assert xp.shape == (5, 8) and cache.padded(f, 8) is xp
+        cache.aggregated(f, xp, g, lambda gg, xx: xx.clone())
+    assert cache.get(ei, 5) is g and len(built) == 1  # the live CSR survived
+    assert len(cache._pads) == 4 and len(cache._aggs) == 4
+    # LRU among CSRs: touch `ei` between other graphs and it stays
+    others = [torch.zeros(2, 3, dtype=torch.int64) for _ in range(5)]
+    for o in others:
+        cache.get(o, 5)
+        assert cache.get(ei, 5) is g
+    assert len(built) == 6 and cache.builds == 6
+    # in-place modification -> rebuilt
+    ei.add_(0)
+    assert cache.get(ei, 5) is not g
+    # dead keys go on the next insert
+    n_before = len(cache._pads)
+    del feats, f, xp
+    cache.padded(torch.randn(5, 7), 8)
+    assert len(cache._pads) <= n_before - 3
+    # temporaries: never stored
+    tmp = torch.randn(5, 48)
+    cache.clear()
+    assert cache.padded(tmp, 64, keep=False).shape == (5, 64) and len(cache._pads) == 0
+    # held_for hands out exactly what belongs to (features, edge_index)
+    x = torch.randn(5, 7)
+    g2 = cache.get(ei, 5)
+    xp = cache.padded(x, 8)
+    agg = cache.aggregated(x, xp, g2, lambda gg, xx: xx.clone())
+    held = cache.held_for(x, ei)
+    assert any(h is g2 for h in held) and any(h is xp for h in held) and any(h is agg for h in held)
+    assert len(held) == 3
