@@ -34,6 +34,13 @@ SIGNATURES = {
                                   _sz, _p]),
     "gsage_segment_gather": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "gsage_segment_gather_skip": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
+    "gsage_segment_gather_live": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
+    "gsage_project_bwd_rows_supported": (C.c_int, [_i64, _i64]),
+    "gsage_project_bwd_rows": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int,
+                                         C.c_float, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _i64, _p]),
+    "gsage_touched_rows_workspace_bytes": (_sz, [_i64]),
+    "gsage_touched_rows": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
+    "gsage_zero_rows": (C.c_int, [_p, _p, _i64, _i64, _p, _p]),
     "gsage_project_workspace_bytes": (_sz, [_i64, _i64]),
     "gsage_project_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int, _p,
                                     C.c_uint64, C.c_float, _p, _p, _p, C.c_int, _p]),

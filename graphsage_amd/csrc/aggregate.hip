@@ -117,7 +117,8 @@ __device__ __forceinline__ void hub_rows(const int *__restrict__ rowptr, const i
                                          const float *__restrict__ ew,
                                          const uint32_t *__restrict__ mask,
                                          const float *__restrict__ x,
-                                         const float *add_to, int64_t F, float *out,
+                                         const float *add_to, const uint32_t *__restrict__ amask,
+                                         int64_t F, float *out,
                                          const int *__restrict__ long_rows,
                                          const int *__restrict__ n_long, int hub_blocks) {
   constexpr int NW = AGG_BLOCK / 64;
@@ -147,7 +148,7 @@ __device__ __forceinline__ void hub_rows(const int *__restrict__ rowptr, const i
       float s = row_scale ? row_scale[row] : 1.f;
       float4 o = make_float4(t.x * s, t.y * s, t.z * s, t.w * s);
       int64_t off = row * F + sub * 4;
-      if (add_to) {
+      if (add_to && (!amask || ((amask[row >> 5] >> (row & 31)) & 1u))) {
         float4 a = *(const float4 *)(add_to + off);
         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
       }
@@ -171,9 +172,10 @@ __device__ __forceinline__ bool masked_flat_rows(const int *__restrict__ rowptr,
                                                  const float *__restrict__ x,
                                                  const float *__restrict__ ew,
                                                  const uint32_t *__restrict__ mask,
-                                                 const float *add_to, int64_t N, int64_t F,
-                                                 int64_t rg, int long_t, int2 *nbr /* [128] */,
-                                                 float4 &keep, float4 &base) {
+                                                 const float *add_to,
+                                                 const uint32_t *__restrict__ amask, int64_t N,
+                                                 int64_t F, int64_t rg, int long_t,
+                                                 int2 *nbr /* [128] */, float4 &keep, float4 &base) {
   constexpr int G = 64 / LPR;
   constexpr int NB = MASK_NB;
   static_assert(G == 2 || G == 4, "flat walk keeps one accumulator per row");
@@ -186,10 +188,13 @@ __device__ __forceinline__ bool masked_flat_rows(const int *__restrict__ rowptr,
   // by a wait for it (the copy into the merged registers), which would put the loads in series.
   // Out-of-range lanes read a clamped address instead and drop the value with a select.
   {
+    // amask: a clear bit says that row of add_to is zero BY PROMISE (it may hold anything):
+    // such a row is neither fetched (the lane reads row 0 of x, a cached line) nor added
     const int64_t rowc = rg + slot < N ? rg + slot : N - 1;
-    const float *bp = add_to ? add_to + rowc * F + sub * 4 : x + sub * 4;
+    const bool have = add_to && (!amask || ((amask[rowc >> 5] >> (rowc & 31)) & 1u));
+    const float *bp = have ? add_to + rowc * F + sub * 4 : x + sub * 4;
     const float4 v = *(const float4 *)bp;
-    base = add_to ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    base = have ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (long_t > 0) {
 #pragma unroll
@@ -271,12 +276,13 @@ template <int LPR, int WMODE, bool MASKED>
 __global__ void __launch_bounds__(AGG_BLOCK, MASKED ? MASK_WAVES : 1)
 seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
                  const float *__restrict__ row_scale, const float *__restrict__ ew,
-                 const uint32_t *__restrict__ mask, const float *__restrict__ x, const float *add_to, int64_t N, int64_t F,
+                 const uint32_t *__restrict__ mask, const float *__restrict__ x, const float *add_to,
+                 const uint32_t *__restrict__ amask, int64_t N, int64_t F,
                  float *out, int long_t, const int *__restrict__ long_rows,
                  const int *__restrict__ n_long, int hub_blocks) {
   if ((int)blockIdx.x < hub_blocks) {
-    hub_rows<LPR, WMODE, MASKED>(rowptr, col, row_scale, ew, mask, x, add_to, F, out, long_rows,
-                                 n_long, hub_blocks);
+    hub_rows<LPR, WMODE, MASKED>(rowptr, col, row_scale, ew, mask, x, add_to, amask, F, out,
+                                 long_rows, n_long, hub_blocks);
     return;
   }
   constexpr int G = 64 / LPR;
@@ -292,7 +298,7 @@ seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
     if constexpr (MASKED && WMODE != 2 && (G == 2 || G == 4)) {
       __shared__ int2 nbr[AGG_BLOCK / 64][128];
       float4 base;
-      if (masked_flat_rows<LPR, WMODE>(rowptr, col, x, ew, mask, add_to, N, F, rg, long_t,
+      if (masked_flat_rows<LPR, WMODE>(rowptr, col, x, ew, mask, add_to, amask, N, F, rg, long_t,
                                        nbr[threadIdx.x >> 6], keep, base)) {
         if (rg + slot < N) {
           const int64_t row = rg + slot;
@@ -322,7 +328,7 @@ seg_gather_vec_k(const int *__restrict__ rowptr, const int *__restrict__ col,
       float s = row_scale ? row_scale[row] : 1.f;
       float4 o = make_float4(keep.x * s, keep.y * s, keep.z * s, keep.w * s);
       int64_t off = row * F + sub * 4;
-      if (add_to) {
+      if (add_to && (!amask || ((amask[row >> 5] >> (row & 31)) & 1u))) {
         float4 a = *(const float4 *)(add_to + off);
         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
       }
@@ -381,7 +387,7 @@ template <int LPR>
 int launch_vec(const int *rowptr, const int *col, const float *row_scale, const float *ew,
                const float *x, const float *add_to, int64_t N, int64_t F, float *out,
                const int *long_rows, const int *n_long, hipStream_t st, bool per_edge,
-               const uint32_t *mask) {
+               const uint32_t *mask, const uint32_t *amask) {
   constexpr int G = 64 / LPR;
   const bool hubs = long_rows && n_long;
   const int long_t = hubs ? gsage_long_row_threshold() : 0;
@@ -390,9 +396,12 @@ int launch_vec(const int *rowptr, const int *col, const float *row_scale, const 
   // rowptr/col/out, which measured 4.5 % faster than a 16384-workgroup grid-stride loop
   const int grid = gs_grid(N, (AGG_BLOCK / 64) * G, 1 << 22) + hub_blocks;
   if (G != 2 && G != 4) mask = nullptr;   // a hint: only the 64- and 128-wide kernels act on it
+  // the add_to mask is NOT a hint (masked rows of add_to may hold anything): the caller has
+  // checked that this width honours it (segment_gather_impl)
 #define GS_LAUNCH_VEC(WM, MK)                                                                      \
   hipLaunchKernelGGL((seg_gather_vec_k<LPR, WM, MK>), dim3(grid), dim3(AGG_BLOCK), 0, st, rowptr, \
-                     col, row_scale, ew, mask, x, add_to, N, F, out, long_t, long_rows, n_long,    \
+                     col, row_scale, ew, mask, x, add_to, amask, N, F, out, long_t, long_rows,     \
+                     n_long,                                                                       \
                      hub_blocks)
   if (ew && per_edge) GS_LAUNCH_VEC(2, false);   // per-entry weights: the mask is not applied
   else if (ew && mask) GS_LAUNCH_VEC(1, true);
@@ -410,20 +419,27 @@ static int segment_gather_impl(const int32_t *rowptr, const int32_t *col, const 
                                const float *edge_weight, bool per_edge, const float *x,
                                const float *add_to, int64_t N, int64_t F, float *out,
                                const int32_t *long_rows, const int32_t *n_long,
-                               const uint32_t *src_mask, gsage_stream_t stream) {
+                               const uint32_t *src_mask, gsage_stream_t stream,
+                               const uint32_t *add_mask = nullptr) {
   if (N < 0 || F <= 0 || !rowptr || !x || !out) return GSAGE_ERR_INVALID_ARG;
+  if (add_mask) {
+    // only the masked 64- and 128-wide kernels read the add_to mask
+    const bool ok = src_mask && add_to && !per_edge && (F == 64 || F == 128) &&
+                    ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)add_to) & 15) == 0);
+    if (!ok) return GSAGE_ERR_UNSUPPORTED;
+  }
   if (N == 0) return GSAGE_OK;
   hipStream_t st = gs_stream(stream);
   bool aligned = (((uintptr_t)x | (uintptr_t)out | (uintptr_t)add_to) & 15) == 0;
   if (aligned) {
     switch (F) {
-      case 4:   return launch_vec<1>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask);
-      case 8:   return launch_vec<2>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask);
-      case 16:  return launch_vec<4>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask);
-      case 32:  return launch_vec<8>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask);
-      case 64:  return launch_vec<16>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask);
-      case 128: return launch_vec<32>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask);
-      case 256: return launch_vec<64>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask);
+      case 4:   return launch_vec<1>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask, add_mask);
+      case 8:   return launch_vec<2>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask, add_mask);
+      case 16:  return launch_vec<4>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask, add_mask);
+      case 32:  return launch_vec<8>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask, add_mask);
+      case 64:  return launch_vec<16>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask, add_mask);
+      case 128: return launch_vec<32>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask, add_mask);
+      case 256: return launch_vec<64>(rowptr, col, row_scale, edge_weight, x, add_to, N, F, out, long_rows, n_long, st, per_edge, src_mask, add_mask);
       default: break;
     }
   }
@@ -460,6 +476,17 @@ extern "C" int gsage_segment_gather_skip(const int32_t *rowptr, const int32_t *c
                                          gsage_stream_t stream) {
   return segment_gather_impl(rowptr, col, row_scale, edge_weight, false, x, add_to, N, F, out,
                              long_rows, n_long, src_nz_mask, stream);
+}
+
+extern "C" int gsage_segment_gather_live(const int32_t *rowptr, const int32_t *col,
+                                         const float *row_scale, const float *edge_weight,
+                                         const float *x, const float *add_to, int64_t N, int64_t F,
+                                         float *out, const int32_t *long_rows,
+                                         const int32_t *n_long, const uint32_t *live_mask,
+                                         gsage_stream_t stream) {
+  if (!live_mask || !add_to) return GSAGE_ERR_INVALID_ARG;
+  return segment_gather_impl(rowptr, col, row_scale, edge_weight, false, x, add_to, N, F, out,
+                             long_rows, n_long, live_mask, stream, live_mask);
 }
 
 extern "C" int gsage_segment_gather_ew(const int32_t *rowptr, const int32_t *col,

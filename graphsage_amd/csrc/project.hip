@@ -867,21 +867,33 @@ proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
 //   [grad_agg | grad_x] = dpre . [W_l | W_r]   (MFMA, weights in registers; grad_agg * scale)
 //   dW += dpre^T . [agg | x], db += colsum     (MFMA over the row index, kept in registers
 //                                               across the workgroup's tiles -> one slab)
-template <int MODE>   // 0 = no epilogue, 1 = ReLU(+dropout), 2 = L2 normalisation
+//
+// ROWS: the tiles are cut from a LIST of row numbers (`rows`, ascending, `*n_rows` entries: the
+// rows a pair batch touched) instead of from all M rows: every other row has grad_out = 0, hence
+// dpre = 0, contributes nothing to dW/db, and its rows of grad_agg / grad_x -- which would be
+// zero -- are NOT written (the transposed gather that follows masks them by the same bits).
+template <int MODE, bool ROWS>   // 0 = no epilogue, 1 = ReLU(+dropout), 2 = L2 normalisation
 __global__ void __launch_bounds__(256, 3)
 bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
               const float *__restrict__ rnorm, const float *__restrict__ agg,
               const float *__restrict__ x, const float *__restrict__ bp /* [128][64] */,
-              const float *__restrict__ agg_scale, int64_t M, float inv_keep,
+              const float *__restrict__ agg_scale, int64_t M_all, float inv_keep,
               float *__restrict__ grad_agg, float *__restrict__ grad_x,
-              float *__restrict__ slabs, uint32_t *__restrict__ nz_mask) {
+              float *__restrict__ slabs, uint32_t *__restrict__ nz_mask,
+              const int *__restrict__ rows, const int *__restrict__ n_rows, int64_t rows_cap) {
   // 32-row tiles, both LDS tiles double-buffered: one barrier per tile, 51 KB per workgroup and
   // <= 168 VGPRs, so three workgroups share a CU and their MFMA phases interleave
   constexpr int TR = 32;
   __shared__ __align__(16) float Ac[2][TR * S64_AP];
   __shared__ __align__(16) float Dp[2][TR * S64_DP];
   __shared__ float sc[2][TR];
+  __shared__ int rid[2][TR];     // ROWS: the tile's row numbers, for the dX stores
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int64_t M = M_all;             // ROWS: entries of the list; else rows of the operands
+  if (ROWS) {
+    M = *n_rows;
+    if (M > rows_cap) M = rows_cap;
+  }
   // dX: wave w owns output columns 32w..32w+31 of [grad_agg | grad_x] for all 32 rows
   float4 breg[8];
 #pragma unroll
@@ -897,12 +909,24 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
   // tile i's operands reach LDS and complete underneath tile i's MFMAs
   float4 gv[2], yv[2], av[2], xv[2];
   float rn[2], scv = 1.f;
+  // ROWS: the row numbers of the tile after the one in flight are fetched a tile ahead (nid),
+  // those of the tile being fetched sit in cid and go to LDS with its operands
+  int nid[2] = {0, 0}, cid[2] = {0, 0}, srow = 0, nsrow = 0;
+#define BWD64_IDS(ROW0)                                                            \
+  if (ROWS) {                                                                      \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                \
+      const int64_t pos = (ROW0) + rsub * 2 + p;                                   \
+      nid[p] = rows[pos < M ? pos : 0];                                            \
+    }                                                                              \
+    if (t < TR) nsrow = rows[(ROW0) + t < M ? (ROW0) + t : 0];                     \
+  }
 #define BWD64_FETCH(ROW0)                                                          \
   {                                                                                \
+    if (ROWS) { cid[0] = nid[0]; cid[1] = nid[1]; srow = nsrow; }                  \
     _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                \
       int64_t row = (ROW0) + rsub * 2 + p;                                         \
       const bool in = row < M;                                                     \
-      row = in ? row : 0;                                                          \
+      row = in ? (ROWS ? (int64_t)cid[p] : row) : 0;                               \
       gv[p] = *(const float4 *)(g + row * 64 + c4);                                \
       if (MODE != 0) yv[p] = *(const float4 *)(y + row * 64 + c4);                 \
       if (MODE == 2) rn[p] = rnorm[row];                                           \
@@ -914,9 +938,14 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
         rn[p] = 0.f;                                                               \
       }                                                                            \
     }                                                                              \
-    if (t < TR) scv = (agg_scale && (ROW0) + t < M) ? agg_scale[(ROW0) + t] : 1.f; \
+    if (t < TR)                                                                    \
+      scv = (agg_scale && (ROW0) + t < M) ? agg_scale[ROWS ? (int64_t)srow : (ROW0) + t] : 1.f; \
   }
-  if ((int64_t)blockIdx.x < ntiles) BWD64_FETCH((int64_t)blockIdx.x * TR)
+  if ((int64_t)blockIdx.x < ntiles) {
+    BWD64_IDS((int64_t)blockIdx.x * TR)
+    BWD64_FETCH((int64_t)blockIdx.x * TR)
+    if ((int64_t)blockIdx.x + gridDim.x < ntiles) BWD64_IDS(((int64_t)blockIdx.x + gridDim.x) * TR)
+  }
   int buf = 0;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
     const int64_t row0 = tile * TR;
@@ -941,11 +970,17 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
       *(float4 *)(Acb + r * S64_AP + c4) = av[p];
       *(float4 *)(Acb + r * S64_AP + 64 + c4) = xv[p];
     }
-    if (t < TR) sc[buf][t] = scv;
+    if (t < TR) {
+      sc[buf][t] = scv;
+      if (ROWS) rid[buf][t] = srow;
+    }
     // the only barrier of the tile: the other buffer was last read before every wave reached
     // the previous one, so the next tile may be staged into it without a second barrier
     __syncthreads();
-    if (tile + gridDim.x < ntiles) BWD64_FETCH((tile + gridDim.x) * TR)
+    if (tile + gridDim.x < ntiles) {
+      BWD64_FETCH((tile + gridDim.x) * TR)
+      if (tile + 2 * (int64_t)gridDim.x < ntiles) BWD64_IDS((tile + 2 * (int64_t)gridDim.x) * TR)
+    }
     // ---- dX (K = 64 dpre columns) and dW (K = the tile's 32 rows), interleaved
     f32x16 a0;
 #pragma unroll
@@ -977,9 +1012,9 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
       for (int k = 0; k < TR; ++k) {
         const float v = Dpb[k * S64_DP + t];
         bsum += v;
-        word |= (__ballot(v != 0.f) != 0ull ? 1u : 0u) << k;
+        if (!ROWS) word |= (__ballot(v != 0.f) != 0ull ? 1u : 0u) << k;
       }
-      if (nz_mask && t == 0) nz_mask[tile] = word;
+      if (!ROWS && nz_mask && t == 0) nz_mask[tile] = word;
     }
     // ---- dX stores straight from the accumulators (128-byte row segments)
     {
@@ -987,13 +1022,14 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int64_t grow = row0 + lr;
+        const int64_t grow = ROWS ? (int64_t)rid[buf][lr] : row0 + lr;
         const float s = w < 2 ? sc[buf][lr] : 1.f;
-        if (grow < M) dst[grow * 64] = a0[r] * s;
+        if (row0 + lr < M) dst[grow * 64] = a0[r] * s;
       }
     }
   }
 #undef BWD64_FETCH
+#undef BWD64_IDS
   float *slab = slabs + (int64_t)blockIdx.x * (64 * 128 + 64);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -1626,14 +1662,19 @@ static __global__ void __launch_bounds__(256) fill_words_k(uint32_t *p, int64_t 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) p[i] = v;
 }
 
-extern "C" int gsage_project_bwd_ex(const float *grad_out, const float *out, const float *rnorm,
-                                    const float *agg, const float *x, const float *w_l,
-                                    const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
-                                    int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
-                                    float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
-                                    void *ws, size_t ws_bytes, int force_generic,
-                                    uint32_t *nz_mask, const uint64_t *relu_sign,
-                                    gsage_stream_t stream) {
+extern "C" int gsage_project_bwd_rows_supported(int64_t Fi, int64_t Fo) {
+  return Fi == 64 && Fo == 64 ? 1 : 0;
+}
+
+static int project_bwd_impl(const float *grad_out, const float *out, const float *rnorm,
+                            const float *agg, const float *x, const float *w_l,
+                            const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
+                            int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
+                            float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
+                            void *ws, size_t ws_bytes, int force_generic,
+                            uint32_t *nz_mask, const uint64_t *relu_sign,
+                            const int32_t *live_rows, const int32_t *n_live, int64_t live_cap,
+                            gsage_stream_t stream) {
   if (N < 0 || Fi <= 0 || Fo <= 0 || !grad_out || !agg || !x || !w_l || !w_r || !grad_w_l ||
       !grad_b || !grad_w_r || !ws)
     return GSAGE_ERR_INVALID_ARG;
@@ -1665,10 +1706,19 @@ extern "C" int gsage_project_bwd_ex(const float *grad_out, const float *out, con
                          fi, fo, wp);
       int grid = nslab < S64_BWD_GRID ? nslab : S64_BWD_GRID;
       const float ik = epilogue == GSAGE_EPI_RELU_DROPOUT ? 1.0f / (1.0f - p) : 1.0f;
-      auto kern = epilogue == GSAGE_EPI_NONE ? bwd64_fused_k<0>
-                  : epilogue == GSAGE_EPI_L2NORM ? bwd64_fused_k<2> : bwd64_fused_k<1>;
+      auto kern = live_rows
+                      ? (epilogue == GSAGE_EPI_NONE ? bwd64_fused_k<0, true>
+                         : epilogue == GSAGE_EPI_L2NORM ? bwd64_fused_k<2, true> : bwd64_fused_k<1, true>)
+                      : (epilogue == GSAGE_EPI_NONE ? bwd64_fused_k<0, false>
+                         : epilogue == GSAGE_EPI_L2NORM ? bwd64_fused_k<2, false> : bwd64_fused_k<1, false>);
+      if (live_rows) {
+        // tiles are cut from the list: no more workgroups than the list can fill
+        const int64_t lt = (live_cap + 31) / 32;
+        if (lt < grid) grid = (int)(lt > 0 ? lt : 1);
+      }
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x,
-                         wp, agg_scale, N, ik, grad_agg, grad_x, slabs, nz_mask);
+                         wp, agg_scale, N, ik, grad_agg, grad_x, slabs, nz_mask, live_rows, n_live,
+                         live_cap);
       GSAGE_CHECK_LAUNCH();
       hipLaunchKernelGGL(reduce_slabs_k, dim3((unsigned)((2 * Fi * Fo + Fo + 63) / 64)), dim3(256), 0,
                          st, slabs, grid, fi, fo, grad_w_l, grad_w_r, grad_b);
@@ -1753,6 +1803,39 @@ extern "C" int gsage_project_bwd_ex(const float *grad_out, const float *out, con
                      slabs, nslab, fi, fo, grad_w_l, grad_w_r, grad_b);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
+}
+
+extern "C" int gsage_project_bwd_ex(const float *grad_out, const float *out, const float *rnorm,
+                                    const float *agg, const float *x, const float *w_l,
+                                    const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,
+                                    int64_t Fo, int epilogue, float p, float *dpre, float *grad_agg,
+                                    float *grad_x, float *grad_w_l, float *grad_b, float *grad_w_r,
+                                    void *ws, size_t ws_bytes, int force_generic,
+                                    uint32_t *nz_mask, const uint64_t *relu_sign,
+                                    gsage_stream_t stream) {
+  return project_bwd_impl(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, N, Fi, Fo, epilogue, p,
+                          dpre, grad_agg, grad_x, grad_w_l, grad_b, grad_w_r, ws, ws_bytes,
+                          force_generic, nz_mask, relu_sign, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int gsage_project_bwd_rows(const float *grad_out, const float *out, const float *rnorm,
+                                      const float *agg, const float *x, const float *w_l,
+                                      const float *w_r, const float *agg_scale, int64_t N,
+                                      int64_t Fi, int64_t Fo, int epilogue, float p, float *grad_agg,
+                                      float *grad_x, float *grad_w_l, float *grad_b,
+                                      float *grad_w_r, void *ws, size_t ws_bytes,
+                                      const int32_t *live_rows, const int32_t *n_live,
+                                      int64_t live_cap, gsage_stream_t stream) {
+  if (!gsage_project_bwd_rows_supported(Fi, Fo)) return GSAGE_ERR_UNSUPPORTED;
+  if (!live_rows || !n_live || live_cap <= 0 || !grad_agg || !grad_x) return GSAGE_ERR_INVALID_ARG;
+  if ((((uintptr_t)grad_out | (uintptr_t)out | (uintptr_t)agg | (uintptr_t)x |
+        (uintptr_t)grad_agg | (uintptr_t)grad_x) & 15) != 0)
+    return GSAGE_ERR_UNSUPPORTED;
+  // dpre never leaves the chip in the fused kernel: any non-null pointer satisfies the check
+  float *dpre_unused = epilogue != GSAGE_EPI_NONE ? grad_agg : nullptr;
+  return project_bwd_impl(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, N, Fi, Fo, epilogue, p,
+                          dpre_unused, grad_agg, grad_x, grad_w_l, grad_b, grad_w_r, ws, ws_bytes, 0,
+                          nullptr, nullptr, live_rows, n_live, live_cap, stream);
 }
 
 extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const float *rnorm,

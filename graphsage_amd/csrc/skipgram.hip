@@ -321,6 +321,111 @@ DetLayout det_layout(int64_t N, int64_t B, int64_t K) {
   return L;
 }
 
+// ------------------------------------------------------------ rows a pair batch touches
+// d(loss)/d(emb) is non-zero only on the rows the batch names (targets, contexts, negatives).
+// They are known before the backward starts: one bit per row, then the sorted list of the set
+// bits, so that the layer behind the loss can walk the touched rows only.
+__global__ void __launch_bounds__(256)
+rows_mark_k(const int64_t *__restrict__ tg, const int64_t *__restrict__ ctx,
+            const int64_t *__restrict__ neg, int64_t B, int64_t K, int64_t N,
+            uint32_t *__restrict__ mask) {
+  const int64_t total = B * (2 + K);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t idx = e < B ? tg[e] : e < 2 * B ? ctx[e - B] : neg[e - 2 * B];
+    if ((uint64_t)idx >= (uint64_t)N) continue;
+    const uint32_t bit = 1u << (idx & 31);
+    uint32_t *w = mask + (idx >> 5);
+    // hub negatives repeat: look before the atomic (a stale read only costs a redundant OR)
+    if (!(__atomic_load_n(w, __ATOMIC_RELAXED) & bit)) atomicOr(w, bit);
+  }
+}
+
+constexpr int RC_BLOCK = 256;   // mask words per workgroup (one per thread)
+
+__global__ void __launch_bounds__(RC_BLOCK)
+rows_count_k(const uint32_t *__restrict__ mask, int64_t nwords, int *__restrict__ block_sums) {
+  __shared__ int red[RC_BLOCK / 64];
+  const int64_t i = (int64_t)blockIdx.x * RC_BLOCK + threadIdx.x;
+  int c = i < nwords ? __popc(mask[i]) : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (gs_lane() == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup: exclusive scan of the block sums in place, total -> n_rows[0]
+__global__ void __launch_bounds__(1024)
+rows_scan_k(int *__restrict__ block_sums, int nblocks, int *__restrict__ n_rows) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + t;
+    const int v = i < nblocks ? block_sums[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int before = carry_s;
+    for (int k = 0; k < w; ++k) before += wsum[k];
+    if (i < nblocks) block_sums[i] = before + inc - v;
+    __syncthreads();
+    if (t == 1023) carry_s = before + inc;
+    __syncthreads();
+  }
+  if (t == 0) n_rows[0] = carry_s;
+}
+
+__global__ void __launch_bounds__(RC_BLOCK)
+rows_emit_k(const uint32_t *__restrict__ mask, int64_t nwords, const int *__restrict__ block_off,
+            int *__restrict__ rows, int64_t cap) {
+  __shared__ int wsum[RC_BLOCK / 64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t i = (int64_t)blockIdx.x * RC_BLOCK + t;
+  uint32_t m = i < nwords ? mask[i] : 0u;
+  const int c = __popc(m);
+  int inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int64_t pos = block_off[blockIdx.x] + inc - c;
+  for (int k = 0; k < w; ++k) pos += wsum[k];
+  const int row0 = (int)(i << 5);
+  while (m) {
+    const int b = __ffs(m) - 1;
+    m &= m - 1;
+    if (pos < cap) rows[pos] = row0 + b;
+    ++pos;
+  }
+}
+
+// zero `n_rows` rows of D floats each, named by a row list (4 rows of 64 floats per wave store)
+__global__ void __launch_bounds__(256)
+rows_zero_k(const int *__restrict__ rows, const int *__restrict__ n_rows, int64_t cap, int64_t D,
+            float *__restrict__ buf) {
+  int64_t n = *n_rows;
+  if (n > cap) n = cap;
+  const int64_t d4 = D / 4;                       // D % 4 == 0 checked by the caller
+  const int64_t total = n * d4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int64_t r = rows[e / d4];
+    *(float4 *)(buf + r * D + (e % d4) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 int sg_blocks(int64_t B, int pairs_per_block) {
   int64_t nb = (B + pairs_per_block - 1) / pairs_per_block;
   if (nb < 1) nb = 1;
@@ -418,6 +523,51 @@ extern "C" int gsage_skipgram_fwd_noalloc(const float *emb, int64_t N, int64_t D
   // rows of this launch's grid, so nothing of the previous call's contents has to be cleared
   return gsage_skipgram_fwd(emb, N, D, targets, contexts, negatives, B, K, scale, loss_norm_B,
                             loss_norm_BK, coef, stats, ptr, sizeof(scratch), stream);
+}
+
+extern "C" size_t gsage_touched_rows_workspace_bytes(int64_t N) {
+  if (N <= 0) return 0;
+  const int64_t nwords = (N + 31) / 32;
+  return gs_align_up((size_t)((nwords + RC_BLOCK - 1) / RC_BLOCK) * sizeof(int), 256);
+}
+
+extern "C" int gsage_touched_rows(const int64_t *targets, const int64_t *contexts,
+                                  const int64_t *negatives, int64_t B, int64_t K, int64_t N,
+                                  uint32_t *mask, int32_t *rows, int64_t rows_cap, int32_t *n_rows,
+                                  void *ws, size_t ws_bytes, gsage_stream_t stream) {
+  if (N <= 0 || B <= 0 || K < 0 || !targets || !contexts || !mask || !rows || !n_rows || !ws ||
+      rows_cap <= 0)
+    return GSAGE_ERR_INVALID_ARG;
+  if (K > 0 && !negatives) return GSAGE_ERR_INVALID_ARG;
+  if (N >= (1ll << 31) - 64) return GSAGE_ERR_UNSUPPORTED;
+  if (ws_bytes < gsage_touched_rows_workspace_bytes(N)) return GSAGE_ERR_WORKSPACE;
+  hipStream_t st = gs_stream(stream);
+  const int64_t nwords = (N + 31) / 32;
+  const int nblocks = (int)((nwords + RC_BLOCK - 1) / RC_BLOCK);
+  int *block_sums = (int *)ws;
+  if (!gs_zero_async(mask, (size_t)nwords * 4, st)) return GSAGE_ERR_LAUNCH;
+  hipLaunchKernelGGL(rows_mark_k, dim3(gs_grid(B * (2 + K), 256, 256 * 16)), dim3(256), 0, st,
+                     targets, contexts, negatives, B, K, N, mask);
+  GSAGE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rows_count_k, dim3(nblocks), dim3(RC_BLOCK), 0, st, mask, nwords, block_sums);
+  GSAGE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rows_scan_k, dim3(1), dim3(1024), 0, st, block_sums, nblocks, n_rows);
+  GSAGE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rows_emit_k, dim3(nblocks), dim3(RC_BLOCK), 0, st, mask, nwords, block_sums,
+                     rows, rows_cap);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}
+
+extern "C" int gsage_zero_rows(const int32_t *rows, const int32_t *n_rows, int64_t rows_cap,
+                               int64_t D, float *buf, gsage_stream_t stream) {
+  if (!rows || !n_rows || !buf || rows_cap <= 0 || D <= 0 || D % 4 != 0 ||
+      (((uintptr_t)buf) & 15) != 0)
+    return GSAGE_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(rows_zero_k, dim3(gs_grid(rows_cap * (D / 4), 256, 256 * 16)), dim3(256), 0,
+                     gs_stream(stream), rows, n_rows, rows_cap, D, buf);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
 }
 
 extern "C" int gsage_skipgram_bwd(const float *emb, int64_t N, int64_t D, const int64_t *targets,

@@ -28,6 +28,9 @@ class SkipGramLoss(nn.Module):
         super().__init__()
         self.scale_factor = scale_factor
         self.deterministic = deterministic
+        # set by an owner that consumes the embedding gradient itself and at once (TrainStep):
+        # the gradient is then built in a persistent all-zero table (ops.GradTable)
+        self.grad_table = None
 
     def _run(self, embeddings, targets, contexts, negatives, global_batch: Optional[int]):
         B = targets.numel()
@@ -35,7 +38,7 @@ class SkipGramLoss(nn.Module):
         gb = B if global_batch is None else int(global_batch)
         return SkipGramFunction.apply(embeddings, targets, contexts, negatives,
                                       float(self.scale_factor), float(gb),
-                                      float(gb * max(K, 1)), self.deterministic)
+                                      float(gb * max(K, 1)), self.deterministic, self.grad_table)
 
     def forward(self, embeddings: torch.Tensor, targets: torch.Tensor, contexts: torch.Tensor,
                 negatives: torch.Tensor, global_batch: Optional[int] = None) -> torch.Tensor:
@@ -54,6 +57,12 @@ class SkipGramLoss(nn.Module):
                              ) -> Tuple[torch.Tensor, Dict[str, float]]:
         loss, stats = self._run(embeddings, targets, contexts, negatives, global_batch)
         return loss, stats_to_details(stats)
+
+
+    def release_grad_table(self) -> None:
+        """Owner's call after the backward pass has consumed the embedding gradient."""
+        if self.grad_table is not None:
+            self.grad_table.release()
 
 
 def stats_to_details(stats: torch.Tensor) -> Dict[str, float]:

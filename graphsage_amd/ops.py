@@ -62,7 +62,7 @@ def set_kernel_timer(timer: Optional[KernelTimer]) -> None:
 
 # ----------------------------------------------------------------------------- raw ops
 def segment_gather(rowptr, col, x, row_scale=None, edge_weight=None, add_to=None, out=None,
-                   long_rows=None, n_long=None, src_nz_mask=None) -> torch.Tensor:
+                   long_rows=None, n_long=None, src_nz_mask=None, live_mask=None) -> torch.Tensor:
     """out[i] = add_to[i] + row_scale[i] * sum_p edge_weight[col[p]] * x[col[p]] (K2/K7).
 
     ``src_nz_mask`` (int32 words, one bit per row of ``x``; a clear bit promises a zero row)
@@ -75,11 +75,24 @@ def segment_gather(rowptr, col, x, row_scale=None, edge_weight=None, add_to=None
         out = torch.empty(N, F, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         # calls that carry a zero-row mask move fewer bytes than the plain gather: timed apart
-        tag = f"segment_gather_F{F}" + ("_skip" if src_nz_mask is not None else "")
+        tag = f"segment_gather_F{F}" + ("_skip" if src_nz_mask is not None or live_mask is not None
+                                        else "")
         ev = _timer.bracket(tag) if _timer is not None and _timer.enabled else None
         if ev:
             ev[0].record()
-        if src_nz_mask is not None:
+        if live_mask is not None:
+            # rows of x AND add_to outside the mask are zero by promise and may hold anything
+            if live_mask.dtype != torch.int32 or live_mask.numel() * 32 < max(x.size(0), N):
+                raise ValueError("live_mask must be int32 with one bit per row of x and add_to")
+            if add_to is None:
+                raise ValueError("live_mask needs add_to")
+            rc = lib.gsage_segment_gather_live(rowptr.data_ptr(), col.data_ptr(),
+                                               _lib.ptr(row_scale), _lib.ptr(edge_weight),
+                                               x.data_ptr(), add_to.data_ptr(), N, F,
+                                               out.data_ptr(), _lib.ptr(long_rows),
+                                               _lib.ptr(n_long), live_mask.data_ptr(),
+                                               _lib.stream_handle())
+        elif src_nz_mask is not None:
             if src_nz_mask.dtype != torch.int32 or src_nz_mask.numel() * 32 < x.size(0):
                 raise ValueError("src_nz_mask must be int32 with one bit per row of x")
             rc = lib.gsage_segment_gather_skip(rowptr.data_ptr(), col.data_ptr(),
@@ -107,14 +120,17 @@ def aggregate_mean(graph: GraphCSR, x: torch.Tensor) -> torch.Tensor:
 
 def aggregate_mean_bwd(graph: GraphCSR, grad_agg: torch.Tensor, prescaled: bool = False,
                        add_to: Optional[torch.Tensor] = None,
-                       nz_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       nz_mask: Optional[torch.Tensor] = None,
+                       live_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """grad_x[j] = add_to[j] + sum_{i in out(j)} grad_agg[i] * inv_deg[i] (K7).
-    ``nz_mask``: the zero-row bits of ``grad_agg`` from :func:`project_bwd`, if any."""
+    ``nz_mask``: the zero-row bits of ``grad_agg`` from :func:`project_bwd`, if any;
+    ``live_mask``: the rows of grad_agg AND add_to that were written at all
+    (:func:`project_bwd_rows`)."""
     out = add_to if add_to is not None else None
     return segment_gather(graph.rowptr_t, graph.col_t, grad_agg,
                           edge_weight=None if prescaled else graph.inv_deg, add_to=add_to,
                           out=out, long_rows=graph.long_rows_t, n_long=graph.n_long[1:2],
-                          src_nz_mask=nz_mask)
+                          src_nz_mask=nz_mask, live_mask=live_mask)
 
 
 def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0, p=0.0,
@@ -160,6 +176,31 @@ def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0
 SKIP_ZERO_ROWS = os.environ.get("GSAGE_SKIP_ZERO_ROWS", "1") != "0"
 
 
+def project_bwd_rows(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue, p,
+                     live: LiveRows):
+    """Backward of K3 over the rows in ``live`` only (gsage_project_bwd_rows).  The rows of
+    grad_agg / grad_x outside the list are NOT written: hand them on with ``live.mask``."""
+    lib = _lib.load()
+    N, Fi = x.shape
+    Fo = w_l.shape[0]
+    dev = x.device
+    with torch.cuda.device(dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        grad_agg, grad_x = torch.empty(N, Fi, **f32), torch.empty(N, Fi, **f32)
+        gwl, gwr, gb = torch.empty(Fo, Fi, **f32), torch.empty(Fo, Fi, **f32), torch.empty(Fo, **f32)
+        ws_bytes = lib.gsage_project_bwd_workspace_bytes(N, Fi, Fo)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = lib.gsage_project_bwd_rows(grad_out.data_ptr(), _lib.ptr(out), _lib.ptr(rnorm),
+                                        agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), w_r.data_ptr(),
+                                        _lib.ptr(agg_scale), N, Fi, Fo, int(epilogue), float(p),
+                                        grad_agg.data_ptr(), grad_x.data_ptr(), gwl.data_ptr(),
+                                        gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(), ws_bytes,
+                                        live.rows.data_ptr(), live.n_rows.data_ptr(), live.cap,
+                                        _lib.stream_handle())
+    _lib.check(rc, "gsage_project_bwd_rows")
+    return grad_agg, grad_x, gwl, gb, gwr
+
+
 def project_bwd(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue, p,
                 need_input_grad: bool, force_generic=False, want_nz_mask: bool = False,
                 relu_sign: Optional[torch.Tensor] = None):
@@ -195,6 +236,86 @@ def project_bwd(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue, p,
     if want_nz_mask:
         return grad_agg, grad_x, gwl, gb, gwr, nz
     return grad_agg, grad_x, gwl, gb, gwr
+
+
+class LiveRows:
+    """The rows of an [N, D] gradient that may be non-zero: bit mask + ascending list + count
+    (all on the device), and the version counter of the tensor they describe."""
+    __slots__ = ("mask", "rows", "n_rows", "cap", "version", "num_rows")
+
+    def __init__(self, mask, rows, n_rows, cap, version, num_rows):
+        self.mask, self.rows, self.n_rows, self.cap = mask, rows, n_rows, cap
+        self.version, self.num_rows = version, num_rows
+
+
+# The gradient of the loss is non-zero only on the rows the pair batch names.  The loss backward
+# says which (LiveRows, attached to the gradient tensor it returns); the 64 -> 64 layer behind it
+# then walks those rows only and the transposed gather masks the rest.  GSAGE_LIVE_ROWS=0 turns
+# the hand-over off (the dense kernels run, with the zero-row ballot of round 1).
+LIVE_ROWS = os.environ.get("GSAGE_LIVE_ROWS", "1") != "0"
+LIVE_STATS = {"made": 0, "used": 0}      # tests / diagnostics
+
+
+def touched_rows(targets, contexts, negatives, N: int) -> LiveRows:
+    """gsage_touched_rows: which rows of an N-row table the batch names."""
+    lib = _lib.load()
+    B = targets.numel()
+    K = negatives.shape[1] if negatives.dim() == 2 else 0
+    dev = targets.device
+    cap = max(1, min(N, (2 + K) * B))
+    with torch.cuda.device(dev):
+        mask = torch.empty((N + 31) // 32, dtype=torch.int32, device=dev)
+        rows = torch.empty(cap, dtype=torch.int32, device=dev)
+        n_rows = torch.empty(1, dtype=torch.int32, device=dev)
+        ws_bytes = lib.gsage_touched_rows_workspace_bytes(N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = lib.gsage_touched_rows(targets.data_ptr(), contexts.data_ptr(),
+                                    negatives.data_ptr() if K > 0 else None, B, K, N,
+                                    mask.data_ptr(), rows.data_ptr(), cap, n_rows.data_ptr(),
+                                    ws.data_ptr(), ws_bytes, _lib.stream_handle())
+    _lib.check(rc, "gsage_touched_rows")
+    return LiveRows(mask, rows, n_rows, cap, 0, N)
+
+
+class GradTable:
+    """A persistent [N, D] buffer for d(loss)/d(emb) that is ALL ZERO between steps: the loss
+    backward adds into the rows its batch names, the consumer reads it, ``release`` clears
+    exactly those rows again -- instead of zero-filling N x D floats every step (2.56 GB at 10 M
+    x 64).  Only for an owner that knows the gradient has one consumer and is not kept
+    (TrainStep): a leaf's ``.grad`` would alias the buffer."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.live: Optional[LiveRows] = None
+        self.dirty = False
+
+    def take(self, like: torch.Tensor) -> torch.Tensor:
+        if self.buf is None or self.buf.shape != like.shape or self.buf.device != like.device:
+            self.buf = torch.zeros_like(like)
+        elif self.dirty:                 # the last user never released it: start clean
+            self.buf.zero_()
+        self.dirty, self.live = True, None
+        return self.buf
+
+    def release(self) -> None:
+        if self.buf is None or not self.dirty:
+            return
+        if self.live is not None:
+            lib = _lib.load()
+            with torch.cuda.device(self.buf.device):
+                rc = lib.gsage_zero_rows(self.live.rows.data_ptr(), self.live.n_rows.data_ptr(),
+                                         self.live.cap, self.buf.size(1), self.buf.data_ptr(),
+                                         _lib.stream_handle())
+            _lib.check(rc, "gsage_zero_rows")
+        else:
+            self.buf.zero_()
+        self.dirty, self.live = False, None
+
+
+def live_rows_worthwhile(N: int, D: int, B: int, K: int) -> bool:
+    """Build the row list only where a consumer exists (the fused 64 -> 64 backward) and the
+    batch cannot touch nearly every row anyway."""
+    return LIVE_ROWS and D == 64 and (2 + K) * B <= 2 * N
 
 
 def skipgram_fwd(emb, targets, contexts, negatives, scale, norm_b=None, norm_bk=None):
@@ -309,6 +430,17 @@ class SAGELayerFunction(torch.autograd.Function):
                 grad_out, out, rnorm, agg, x, w_l, w_r, None, ctx.epilogue, ctx.p, True,
                 ctx.force_generic)
             return (grad_x if need_x else None), gwl, gb, gwr, None, None, None, None, None, None, grad_agg
+        live = getattr(grad_out, "_gsage_live", None)
+        if (live is not None and need_x and not ctx.force_generic and SKIP_ZERO_ROWS
+                and live.version == grad_out._version and live.num_rows == x.size(0)
+                and _lib.load().gsage_project_bwd_rows_supported(x.size(1), w_l.size(0))):
+            # the loss backward listed the rows of grad_out that can be non-zero: walk only those
+            LIVE_STATS["used"] += 1
+            grad_agg, grad_x, gwl, gb, gwr = project_bwd_rows(
+                grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p, live)
+            grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x,
+                                        live_mask=live.mask)
+            return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None
         grad_agg, grad_x, gwl, gb, gwr, nz = project_bwd(
             grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p,
             need_x, ctx.force_generic, want_nz_mask=True, relu_sign=sign)
@@ -323,7 +455,8 @@ class SkipGramFunction(torch.autograd.Function):
     """K4 forward / K5 backward.  Returns (loss 0-dim, stats[8])."""
 
     @staticmethod
-    def forward(ctx, emb, targets, contexts, negatives, scale, norm_b, norm_bk, deterministic=None):
+    def forward(ctx, emb, targets, contexts, negatives, scale, norm_b, norm_bk, deterministic=None,
+                grad_table: Optional[GradTable] = None):
         emb = _f32c(emb, "embeddings")
         targets, contexts = _i64c(targets, "targets"), _i64c(contexts, "contexts")
         negatives = _i64c(negatives, "negatives")
@@ -336,6 +469,7 @@ class SkipGramFunction(torch.autograd.Function):
         coef, stats = skipgram_fwd(emb, targets, contexts, negatives, scale, norm_b, norm_bk)
         ctx.save_for_backward(emb, targets, contexts, negatives, coef)
         ctx.deterministic = deterministic
+        ctx.grad_table = grad_table
         loss = stats[0].clone()
         ctx.mark_non_differentiable(stats)
         return loss, stats
@@ -344,9 +478,28 @@ class SkipGramFunction(torch.autograd.Function):
     def backward(ctx, grad_loss, _grad_stats):
         emb, targets, contexts, negatives, coef = ctx.saved_tensors
         g = grad_loss.to(torch.float32).contiguous()
+        K = coef.shape[1] - 1
+        N, B = emb.size(0), targets.numel()
+        want_live = live_rows_worthwhile(N, emb.size(1), B, K)
+        det = ctx.deterministic if ctx.deterministic is not None else loss_bwd_deterministic(N, B, K)
+        table = ctx.grad_table if (want_live and not det and emb.size(1) % 4 == 0) else None
         grad_emb = skipgram_bwd(emb, targets, contexts, negatives, coef, g,
-                                deterministic=ctx.deterministic)
-        return grad_emb, None, None, None, None, None, None, None
+                                grad_emb=table.take(emb) if table is not None else None,
+                                deterministic=det)
+        if want_live:
+            # rows outside the batch are exactly zero in grad_emb: tell the consumer which
+            live = touched_rows(targets, contexts, negatives, N)
+            live.version = grad_emb._version
+            try:                         # a fresh attribute each step on the persistent buffer
+                grad_emb._gsage_live = live
+            except AttributeError:       # pragma: no cover
+                pass
+            if table is not None:
+                table.live = live
+            LIVE_STATS["made"] += 1
+        elif hasattr(grad_emb, "_gsage_live"):
+            del grad_emb._gsage_live
+        return grad_emb, None, None, None, None, None, None, None, None
 
 
 class RowSubsetMean(torch.autograd.Function):

@@ -66,6 +66,11 @@ class TrainStep:
         self.edge_index = edge_index
         self.gradient_clip = gradient_clip
         self.loss_fn = loss_fn if loss_fn is not None else SkipGramLoss(scale_factor)
+        if loss_fn is None and features.is_cuda:
+            # the embedding gradient of a step has one consumer (the model's last layer) and is
+            # not kept: build it in a persistent table that is cleared row-wise, not zero-filled
+            from .ops import GradTable
+            self.loss_fn.grad_table = GradTable()
         self.flat = FlatParams(model)
         # capturable: the step counter lives on the device, so the optimiser can sit inside a
         # captured HIP graph (capture_step below) as well as run eagerly
@@ -103,6 +108,7 @@ class TrainStep:
         loss, stats = self.loss_fn.forward_stats(emb, targets, contexts, negatives,
                                                  global_batch=global_batch)
         loss.backward()
+        self._release_grad_table()
         self.flat.extra.copy_(stats)
         if self.world > 1:
             self._all_reduce_flat()
@@ -185,10 +191,16 @@ class TrainStep:
         loss, stats = self.loss_fn.forward_stats(emb, self._gt, self._gc, self._gn,
                                                  global_batch=batch_size)
         loss.backward()
+        self._release_grad_table()
         self.flat.extra.copy_(stats)
         if self.gradient_clip > 0:
             torch.nn.utils.clip_grad_norm_([self.flat.flat_param], self.gradient_clip)
         self.optimizer.step()
+
+    def _release_grad_table(self) -> None:
+        rel = getattr(self.loss_fn, "release_grad_table", None)
+        if rel is not None:
+            rel()
 
     def step_captured(self, targets, contexts, negatives) -> torch.Tensor:
         """Replay the captured step on a new batch (copied into the graph's static inputs)."""

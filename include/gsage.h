@@ -110,6 +110,16 @@ int gsage_segment_gather_skip(const int32_t *rowptr, const int32_t *col,
                               float *out, const int32_t *long_rows, const int32_t *n_long,
                               const uint32_t *src_nz_mask, gsage_stream_t stream);
 
+/* Same again, for the case where the rows of BOTH x and add_to outside a set are zero by promise
+ * and may hold anything (gsage_project_bwd_rows does not write them): bit r of live_mask clear =>
+ * row r of x and row r of add_to count as zero and are not fetched.  F must be 64 or 128, add_to
+ * non-NULL (GSAGE_ERR_UNSUPPORTED otherwise: the mask is not a hint here). */
+int gsage_segment_gather_live(const int32_t *rowptr, const int32_t *col,
+                              const float *row_scale, const float *edge_weight,
+                              const float *x, const float *add_to, int64_t N, int64_t F,
+                              float *out, const int32_t *long_rows, const int32_t *n_long,
+                              const uint32_t *live_mask, gsage_stream_t stream);
+
 /* Weighted variant: out[i,:] = sum_{p in row i} edge_w[p] * x[col[p],:] with one weight per
  * CSR entry (same order as col).  Used by the deterministic loss backward; also the SpMM a
  * weighted graph would need. */
@@ -184,6 +194,23 @@ int gsage_project_bwd_ex(const float *grad_out, const float *out, const float *r
                          void *ws, size_t ws_bytes, int force_generic, uint32_t *nz_mask,
                          const uint64_t *relu_sign, gsage_stream_t stream);
 
+/* The backward restricted to the rows a pair batch touched (gsage_touched_rows): autograd hands
+ * the layer behind the loss a dense [N,Fo] gradient in which only those rows are non-zero
+ * (loss.py:97-103 under autograd: three index_put(accumulate) into zeros), and PyG's backward
+ * then pushes all N rows through the GEMMs.  Here the 32-row tiles are cut from the sorted list
+ * `live_rows` (`*n_live` entries on the device, at most live_cap): rows outside it contribute
+ * nothing to grad_w_l / grad_w_r / grad_b and are neither read nor written -- their rows of
+ * grad_agg / grad_x are left as they are and must be masked by the consumer
+ * (gsage_segment_gather_live).  Same results as gsage_project_bwd_ex on the listed rows and for
+ * the weight gradients.  Only where gsage_project_bwd_rows_supported(Fi, Fo) (64 -> 64). */
+int gsage_project_bwd_rows_supported(int64_t Fi, int64_t Fo);
+int gsage_project_bwd_rows(const float *grad_out, const float *out, const float *rnorm,
+                           const float *agg, const float *x, const float *w_l, const float *w_r,
+                           const float *agg_scale, int64_t N, int64_t Fi, int64_t Fo, int epilogue,
+                           float p, float *grad_agg, float *grad_x, float *grad_w_l, float *grad_b,
+                           float *grad_w_r, void *ws, size_t ws_bytes, const int32_t *live_rows,
+                           const int32_t *n_live, int64_t live_cap, gsage_stream_t stream);
+
 /* ---------------------------------------------------------- K4 / K5: skip-gram loss
  * K4 replaces SkipGramLoss.forward / forward_with_details (src/model/loss.py:97-136,
  * 161-193): three row gathers, B + B*K dots, x scale, logsigmoid means, and the
@@ -215,6 +242,20 @@ int gsage_skipgram_bwd(const float *emb, int64_t N, int64_t D, const int64_t *ta
                        const int64_t *contexts, const int64_t *negatives, int64_t B,
                        int64_t K, const float *coef, const float *grad_loss,
                        float *grad_emb, gsage_stream_t stream);
+
+/* The rows of the embedding table a pair batch names, i.e. the only rows where K5's gradient is
+ * non-zero (loss.py:97-103).  mask: uint32 [ceil(N/32)], bit r%32 of word r/32 set iff row r is a
+ * target, context or negative of the batch (out-of-range ids are ignored); rows: the set bits as
+ * an ascending int32 list (first min(*n_rows, rows_cap) entries valid; rows_cap = min(N, (2+K)B)
+ * always suffices); n_rows: int32 [1] on the device.  ws: gsage_touched_rows_workspace_bytes(N).
+ * gsage_zero_rows clears exactly those rows of a [*, D] fp32 buffer (D % 4 == 0). */
+size_t gsage_touched_rows_workspace_bytes(int64_t N);
+int gsage_touched_rows(const int64_t *targets, const int64_t *contexts, const int64_t *negatives,
+                       int64_t B, int64_t K, int64_t N, uint32_t *mask, int32_t *rows,
+                       int64_t rows_cap, int32_t *n_rows, void *ws, size_t ws_bytes,
+                       gsage_stream_t stream);
+int gsage_zero_rows(const int32_t *rows, const int32_t *n_rows, int64_t rows_cap, int64_t D,
+                    float *buf, gsage_stream_t stream);
 
 /* K4 for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers
  * that must not (or cannot) call hipMalloc or bring a workspace -- code under HIP graph capture,
