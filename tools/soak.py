@@ -17,7 +17,9 @@ def run(n, B, steps, captured, deterministic):
     x = memory_features(n, seed=1, device="cuda")
     torch.manual_seed(0)
     m = GraphSAGE(7, 64, 64, 2, 0.3).cuda()
-    ts = TrainStep(m, x, ei, loss_fn=SkipGramLoss(deterministic=deterministic))
+    # "default": TrainStep's own loss (persistent gradient table + touched-row hand-over)
+    ts = TrainStep(m, x, ei) if deterministic == "default" else \
+        TrainStep(m, x, ei, loss_fn=SkipGramLoss(deterministic=deterministic))
     batches = [cooccurrence_batch(ei, n, B, 5, seed=s) for s in range(8)]
     if captured:
         ts.capture_step(B, 5, preserve_state=True)
@@ -41,4 +43,7 @@ if __name__ == "__main__":
     good &= run(500, 1024, 5000, True, True)
     good &= run(100_000, 1 << 17, 3000, False, None)
     good &= run(100_000, 1 << 16, 3000, True, None)
+    good &= run(500, 128, 20000, True, "default")            # touched-row path, captured
+    good &= run(1_000_000, 1 << 14, 3000, True, "default")   # rows list much shorter than N
+    good &= run(1_000_000, 1 << 14, 2000, False, "default")
     sys.exit(0 if good else 1)
