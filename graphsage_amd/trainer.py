@@ -104,6 +104,29 @@ class BatchGenerator:
             yield Batch(t, c, neg, hi - lo)
 
 
+class EarlyStopping:
+    """The stopping rule of the reference's ``EarlyStopping`` in 'min' mode
+    (``src/training/callbacks.py:18-84``): a value counts as an improvement only when it beats
+    the rule's OWN best by more than ``min_delta``, and only then does that best (and
+    ``best_epoch``) move -- so a slow steady descent adds up and eventually registers, where a
+    comparison against the running minimum would never see it."""
+
+    def __init__(self, patience: int = 10, min_delta: float = 0.0001):
+        self.patience, self.min_delta = patience, min_delta
+        self.best_value = float("inf")
+        self.counter = self.best_epoch = self.stopped_epoch = 0
+
+    def __call__(self, value: float, epoch: int = 0) -> bool:
+        if value < self.best_value - self.min_delta:
+            self.best_value, self.best_epoch, self.counter = value, epoch, 0
+            return False
+        self.counter += 1
+        if self.counter >= self.patience:
+            self.stopped_epoch = epoch
+            return True
+        return False
+
+
 class GraphSAGETrainer:
     """Same constructor and methods as the reference trainer; the step itself is
     :class:`TrainStep` (flat gradient buffer, clip, Adam, optional RCCL all-reduce)."""
@@ -201,7 +224,7 @@ class GraphSAGETrainer:
 
     def train(self, num_epochs: int) -> float:
         """``trainer.py:299-364``: epochs with validation, best-model checkpoint, early stop."""
-        wait = 0
+        self.early_stopping = EarlyStopping(self.patience, self.min_delta)
         for epoch in range(num_epochs):
             self.current_epoch = epoch
             t0 = time.time()
@@ -212,9 +235,8 @@ class GraphSAGETrainer:
                                  "seconds": time.time() - t0})
             if self.verbose:
                 print(f"epoch {epoch}: train {train_metrics['loss']:.4f} val {monitor:.4f}")
-            improved = monitor < self.best_loss - self.min_delta
-            if monitor < self.best_loss:
-                self.best_loss, self.best_epoch = monitor, epoch
+            if monitor < self.best_loss:          # plain minimum, trainer.py:345-346
+                self.best_loss = monitor
                 if self.checkpoint_dir:
                     os.makedirs(self.checkpoint_dir, exist_ok=True)
                     self.save_checkpoint(os.path.join(self.checkpoint_dir, "model_best.pt"),
@@ -223,8 +245,9 @@ class GraphSAGETrainer:
             if self.checkpoint_dir and self.checkpoint_every and (epoch + 1) % self.checkpoint_every == 0:
                 self.save_checkpoint(os.path.join(self.checkpoint_dir, f"model_epoch{epoch + 1}.pt"),
                                      value=monitor)
-            wait = 0 if improved else wait + 1
-            if wait >= self.patience:
+            stop = self.early_stopping(monitor, epoch)          # trainer.py:349
+            self.best_epoch = self.early_stopping.best_epoch    # as the reference logs it (:358)
+            if stop:
                 break
         return self.best_loss
 

@@ -174,3 +174,20 @@ def test_graph_cache_keeps_the_live_csr_whatever_else_is_cached(monkeypatch):
     held = cache.held_for(x, ei)
     assert any(h is g2 for h in held) and any(h is xp for h in held) and any(h is agg for h in held)
     assert len(held) == 3
+
+
+def test_early_stopping_rule_is_the_references():
+    """callbacks.py:69-84: improvement is measured against the rule's own best, which moves only
+    on an improvement > min_delta.  A loss falling by less than min_delta per epoch eventually
+    registers (the reference continues); a running-minimum comparison would stop after `patience`."""
+    from graphsage_amd.trainer import EarlyStopping
+    es = EarlyStopping(patience=3, min_delta=0.01)
+    values = [1.0 - 0.004 * i for i in range(12)]          # -0.004 per epoch < min_delta
+    stops = [es(v, i) for i, v in enumerate(values)]
+    # epochs 1, 2 do not register (0.996, 0.992 > 1.0 - 0.01); epoch 3 (0.988) does, and so on
+    assert stops == [False] * 12
+    assert es.best_epoch == 9 and abs(es.best_value - values[9]) < 1e-12
+    es2 = EarlyStopping(patience=3, min_delta=0.01)
+    flat = [1.0, 0.999, 0.9985, 0.998, 0.9979]
+    assert [es2(v, i) for i, v in enumerate(flat)] == [False, False, False, True, True]
+    assert es2.best_epoch == 0 and es2.stopped_epoch == 4
