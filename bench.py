@@ -271,12 +271,50 @@ def cpu_baseline(args, hidden, out_dim, layers, K, inference=False):
         if time.perf_counter() - t0 > 30.0:
             break
     dt = (time.perf_counter() - t0) / steps
-    return {
+    out = {
         "value": b / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
         "sample": f"{n}-node/{ei.size(1)}-edge graph from the same generator (1/{max(nodes_full // n, 1)} "
                   f"of the workload), {b} pairs/step (same pairs per node), {steps} steps, "
                   f"{dt * 1e3:.1f} ms/step",
     }
+    if args.workload == "c4" and not args.nodes:
+        out["full_size_configs"] = cpu_full_size_configs(K)
+    return out
+
+
+def cpu_full_size_configs(K):
+    """the CPU path on BASELINE configs 1 and 2 IN FULL (they fit the host), at the
+    reference's own batch of 1024 pairs; a few seconds in all."""
+    import numpy as np
+    import torch
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    from oracle import sage_oracle as O
+    res = []
+    z = np.load(os.path.join(ROOT, "tests", "golden", "c1_graph.npz"))
+    graphs = [("C1: the reference's default 500-node graph (generator seed 42)",
+               torch.from_numpy(z["edge_index"]), torch.from_numpy(z["features"]).float(), 200),
+              ("C2: 100k-node/~2M-edge power-law graph", powerlaw_graph(100_000, 20, seed=42),
+               memory_features(100_000, seed=42), 8)]
+    threads = torch.get_num_threads()
+    for name, ei, x, max_steps in graphs:
+        n = x.size(0)
+        used = min(threads, 4) if n < 10_000 else threads    # a 500-node step gains nothing beyond
+        torch.set_num_threads(used)
+        torch.manual_seed(0)
+        model = O.OracleGraphSAGE(7, 64, 64, 2, 0.3).train()
+        opt = O.make_adam(model)
+        batches = [cooccurrence_batch(ei, n, 1024, K, seed=s) for s in range(2)]
+        O.train_step(model, opt, x, ei, *batches[0])
+        steps, t0 = 0, time.perf_counter()
+        while steps < max_steps and time.perf_counter() - t0 < 5.0:
+            O.train_step(model, opt, x, ei, *batches[steps % 2])
+            steps += 1
+        dt = (time.perf_counter() - t0) / steps
+        res.append({"config": name, "nodes": n, "edges": int(ei.size(1)), "pairs_per_step": 1024,
+                    "ms_per_step": dt * 1e3, "pairs_per_s": 1024 / dt, "steps": steps,
+                    "cores": used})
+    torch.set_num_threads(threads)
+    return res
 
 
 # ------------------------------------------------------------------- launch-path self-test
