@@ -410,9 +410,14 @@ def run_training(args, R):
                 "traffic_stale": stale, "csrc_hash": csrc_hash(),
                 "launches_timed": launches, "mean_ms": mean_ms, "algorithmic_bytes": alg_bytes}
     if skip_launches:
+        m_traffic, _, _ = measured_traffic(args.workload, f"seg_gather_vec_k<{F // 4}, 0, true>") \
+            if not args.nodes else (None, None, None)
         roofline["masked_backward_gather"] = {
             "kernel": f"seg_gather_vec_k<{F // 4},0,masked>: rows whose gradient is zero are not fetched",
-            "launches_timed": skip_launches, "mean_ms": skip_ms}
+            "launches_timed": skip_launches, "mean_ms": skip_ms, "traffic": m_traffic,
+            # it moves fewer bytes than the algorithmic count, so its rate is quoted on the bytes
+            # the counters saw (same profile file as roofline.traffic)
+            "measured_traffic_GBs": m_traffic / (skip_ms * 1e-3) / 1e9 if m_traffic else None}
 
     # the batch the reference would actually train with (config/config.yaml:37, trainer.py:108):
     # a short second timed loop on the same graph, model and harness, eager
