@@ -8,11 +8,14 @@ from .train_step import TrainStep, FlatParams, shard_bounds
 from .sampler import DegreeBiasedNegativeSampler, UniformNegativeSampler
 from .encoder import StructuralEncoder, model_from_checkpoint
 from .walks import RandomWalkGenerator, CooccurrencePairSampler, estimate_pair_count
-from .trainer import GraphSAGETrainer, BatchGenerator, Batch, split_pairs_train_val
+from .trainer import (GraphSAGETrainer, BatchGenerator, StreamingBatchGenerator, Batch,
+                      split_pairs_train_val)
+from .datafiles import load_training_data, save_training_data, load_walks
 
 __all__ = ["GraphSAGE", "SAGEConv", "create_model", "SkipGramLoss", "create_loss", "GraphCSR",
            "GraphCache", "build_csr", "default_cache", "TrainStep", "FlatParams", "shard_bounds", "DegreeBiasedNegativeSampler",
            "UniformNegativeSampler", "GraphSAGETrainer", "BatchGenerator", "Batch",
            "split_pairs_train_val", "StructuralEncoder", "model_from_checkpoint",
-           "RandomWalkGenerator", "CooccurrencePairSampler", "estimate_pair_count"]
+           "RandomWalkGenerator", "CooccurrencePairSampler", "estimate_pair_count",
+           "StreamingBatchGenerator", "load_training_data", "save_training_data", "load_walks"]
 __version__ = "0.1.0"

@@ -271,3 +271,58 @@ class GraphSAGETrainer:
         self._graph_ready = False        # the optimiser state tensors may be new objects: recapture
         self.current_epoch = ckpt.get("epoch", 0)
         self.best_loss = ckpt.get("best_loss", float("inf"))
+
+
+class StreamingBatchGenerator:
+    """Counterpart of ``StreamingBatchGenerator`` (``batch_generator.py:205-309``): batches of
+    pairs streamed out of the walks instead of a materialised pair list -- every pair of every
+    walk exactly once per epoch, walks visited in a fresh random order, pairs of a walk in the
+    reference's order (position i, then window slot j), batches of exactly ``batch_size`` pairs
+    except the last.  The reference runs a triple Python loop with list buffers; here the walks
+    are the device tensor of :class:`RandomWalkGenerator`, a batch is pair numbers
+    ``[b*B, (b+1)*B)`` of the permuted walks decoded by one kernel (``gsage_walk_pairs_gather``)
+    and the negatives come from one more (``gsage_alias_sample``)."""
+
+    def __init__(self, walks, context_window: int, negative_sampler, batch_size: int = 512,
+                 num_negatives: int = 5, device=None, lengths: Optional[torch.Tensor] = None,
+                 shuffle: bool = True):
+        """``walks``: int32 ``[W, L]`` tensor padded with -1 plus ``lengths`` (what
+        ``RandomWalkGenerator.generate_all_walks`` returns), or the reference's list of lists."""
+        from .walks import CooccurrencePairSampler
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        if not torch.is_tensor(walks):
+            L = max((len(w) for w in walks), default=1)
+            lengths = torch.tensor([len(w) for w in walks], dtype=torch.int32)
+            walks = torch.tensor([list(w) + [-1] * (L - len(w)) for w in walks],
+                                 dtype=torch.int32).reshape(len(lengths), L)
+        elif lengths is None:
+            lengths = (walks >= 0).sum(1).to(torch.int32)
+        self.walks = walks.to(self.device, torch.int32).contiguous()
+        self.lengths = lengths.to(self.device, torch.int32).contiguous()
+        self.context_window = context_window
+        self.negative_sampler = negative_sampler
+        self.batch_size, self.num_negatives, self.shuffle = batch_size, num_negatives, shuffle
+        self._pairs = CooccurrencePairSampler(context_window)
+        self.walk_order: Optional[torch.Tensor] = None   # a fixed visiting order (tests)
+        # batch_generator.py:243-251: walk_len * min(2*window, walk_len - 1), an upper estimate
+        n = self.lengths.to(torch.int64)
+        self.estimated_pairs = int((n * torch.clamp(n - 1, max=2 * context_window)).sum().item())
+
+    def __iter__(self) -> Iterator[Batch]:
+        W = self.lengths.numel()
+        if W == 0:
+            return
+        walks, lengths = self.walks, self.lengths
+        if self.walk_order is not None or self.shuffle:   # batch_generator.py:259-261
+            perm = self.walk_order.to(self.device) if self.walk_order is not None else \
+                torch.randperm(W, device=self.device)
+            walks, lengths = walks[perm].contiguous(), lengths[perm].contiguous()
+        offsets = self._pairs.index(walks, lengths)
+        total = int(offsets[-1].item())
+        for lo in range(0, total, self.batch_size):
+            size = min(self.batch_size, total - lo)
+            t, c = self._pairs._gather(walks, lengths, offsets, None, lo, size)
+            neg = self.negative_sampler.sample(size, self.num_negatives)
+            if neg.device != self.device:
+                neg = neg.to(self.device)
+            yield Batch(t, c, neg, size)

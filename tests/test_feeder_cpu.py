@@ -112,3 +112,54 @@ def test_oracle_pair_window_matches_reference_golden(golden_dir):
     # pair_sampler.py:287-305: every position sees at most 2*window others
     assert len(O.extract_pairs([[3]], 5)) == 0
     assert len(O.extract_pairs([list(range(30))], 10)) <= 30 * 20
+
+
+def _stream_walks(z):
+    out, p = [], 0
+    flat = z["walk_flat"].tolist()
+    for n in z["walk_len"].tolist():
+        out.append(flat[p:p + n])
+        p += n
+    return out
+
+
+def test_oracle_pair_stream_matches_reference_streaming_generator(golden_dir):
+    """stream_golden.npz = the batches the reference's own StreamingBatchGenerator
+    (batch_generator.py:205-309) produced: its stream is the pair list of the walks taken in the
+    shuffled order, cut every batch_size pairs.  Pins oracle.extract_pairs on ragged walks."""
+    z = np.load(os.path.join(golden_dir, "stream_golden.npz"))
+    walks = _stream_walks(z)
+    for tag in ("a", "b", "c"):
+        w, bs = int(z[f"{tag}.window"]), int(z[f"{tag}.batch_size"])
+        pairs = O.extract_pairs([walks[i] for i in z[f"{tag}.order"].tolist()], w)
+        assert [p[0] for p in pairs] == z[f"{tag}.targets"].tolist()
+        assert [p[1] for p in pairs] == z[f"{tag}.contexts"].tolist()
+        sizes = z[f"{tag}.sizes"].tolist()
+        assert sizes == [bs] * (len(pairs) // bs) + ([len(pairs) % bs] if len(pairs) % bs else [])
+        est = sum(len(x) * min(2 * w, len(x) - 1) for x in walks)
+        assert est == int(z[f"{tag}.estimated_pairs"])
+
+
+def test_training_data_directory_round_trip(tmp_path):
+    """features.pt / edge_index.pt / pairs.pt / metadata.json / walks/walks.json as
+    scripts/generate_data.py:175-212 writes them and scripts/train.py:74-99 reads them."""
+    import json
+    from graphsage_amd import load_training_data, load_walks, save_training_data
+    x = torch.rand(30, 7)
+    ei = torch.randint(0, 30, (2, 90))
+    t, c = torch.randint(0, 30, (200,)), torch.randint(0, 30, (200,))
+    d = str(tmp_path / "processed")
+    save_training_data(d, x, ei, t, c, metadata={"seed": 42}, walks=[[0, 1, 2], [3, 4]])
+    # the reference's own reader lines (train.py:79-88), weights_only for safety
+    assert torch.equal(torch.load(os.path.join(d, "features.pt"), weights_only=True), x)
+    assert torch.equal(torch.load(os.path.join(d, "edge_index.pt"), weights_only=True), ei)
+    pd = torch.load(os.path.join(d, "pairs.pt"), weights_only=True)
+    assert set(pd) == {"targets", "contexts"} and pd["targets"].dtype == torch.int64
+    meta = json.load(open(os.path.join(d, "metadata.json")))
+    assert meta["num_nodes"] == 30 and meta["num_edges"] == 90 and meta["seed"] == 42
+    fx, fe, (ft, fc), fm = load_training_data(d, device="cpu")
+    assert torch.equal(fx, x) and torch.equal(fe, ei) and torch.equal(ft, t) and torch.equal(fc, c)
+    assert fm == meta and load_walks(d) == [[0, 1, 2], [3, 4]]
+    # and a directory written the reference's way (pairs as int32 lists turned tensors) loads too
+    torch.save({"targets": t.to(torch.int32), "contexts": c.to(torch.int32)}, os.path.join(d, "pairs.pt"))
+    assert load_training_data(d, device="cpu")[2][0].dtype == torch.int64

@@ -121,3 +121,42 @@ def test_batch_generator_epoch_semantics_on_device():
     b0 = batches[0]
     loss, det = SkipGramLoss().forward_with_details(emb, b0.targets, b0.contexts, b0.negatives)
     assert np.isfinite(det["total_loss"]) and det["total_loss"] > 0
+
+
+def test_streaming_batch_generator_reproduces_the_reference_stream(golden_dir):
+    """Device StreamingBatchGenerator vs the batches the reference's own class produced
+    (stream_golden.npz, batch_generator.py:205-309): given the walk order the reference drew,
+    every batch is identical; with its own shuffle every pair still appears exactly once."""
+    from graphsage_amd import StreamingBatchGenerator, UniformNegativeSampler
+    z = np.load(os.path.join(golden_dir, "stream_golden.npz"))
+    walks, p = [], 0
+    flat = z["walk_flat"].tolist()
+    for n in z["walk_len"].tolist():
+        walks.append(flat[p:p + n])
+        p += n
+    neg = UniformNegativeSampler(50, device=torch.device("cuda"))
+    for tag in ("a", "b", "c"):
+        w, bs = int(z[f"{tag}.window"]), int(z[f"{tag}.batch_size"])
+        gen = StreamingBatchGenerator(walks, w, neg, batch_size=bs, num_negatives=2, device="cuda")
+        assert gen.estimated_pairs == int(z[f"{tag}.estimated_pairs"])
+        gen.walk_order = torch.from_numpy(z[f"{tag}.order"])
+        batches = list(gen)
+        assert [b.size for b in batches] == z[f"{tag}.sizes"].tolist()
+        assert torch.cat([b.targets for b in batches]).cpu().tolist() == z[f"{tag}.targets"].tolist()
+        assert torch.cat([b.contexts for b in batches]).cpu().tolist() == z[f"{tag}.contexts"].tolist()
+        assert all(b.negatives.shape == (b.size, 2) and b.negatives.is_cuda for b in batches)
+        gen.walk_order = None
+        again = list(gen)
+        key = lambda bb: sorted(zip(torch.cat([b.targets for b in bb]).cpu().tolist(),
+                                    torch.cat([b.contexts for b in bb]).cpu().tolist()))
+        assert key(again) == key(batches)
+    # tensor form straight from the device walker, on a graph
+    from graphsage_amd import CooccurrencePairSampler, RandomWalkGenerator
+    from graphsage_amd.synth import powerlaw_graph
+    ei = powerlaw_graph(300, 6, seed=1).cuda()
+    wk, ln = RandomWalkGenerator(ei, 300, walk_length=12, walks_per_node=2, seed=5).generate_all_walks()
+    gen = StreamingBatchGenerator(wk, 3, neg, batch_size=500, device="cuda", lengths=ln, shuffle=False)
+    t_all, c_all = CooccurrencePairSampler(3).extract_pairs_tensor(wk, ln)
+    bb = list(gen)
+    assert torch.equal(torch.cat([b.targets for b in bb]), t_all)
+    assert torch.equal(torch.cat([b.contexts for b in bb]), c_all)
