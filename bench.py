@@ -400,15 +400,16 @@ def run_training(args, R):
     launches, mean_ms = timer.summary().get(f"segment_gather_F{F}", (0, float("nan")))
     skip_launches, skip_ms = timer.summary().get(f"segment_gather_F{F}_skip", (0, float("nan")))
     alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F
-    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if launches else float("nan")
+    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if launches else None
     kname = f"seg_gather_vec_k<{F // 4}, 0, false>"
     traffic, traffic_src, stale = measured_traffic(args.workload, kname) if not args.nodes \
         else (None, None, None)
     roofline = {"bound": "hbm", "kernel": f"{kname} (hub rows included), F={F}",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": achieved / HBM_PEAK_GBS if launches else None, "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_stale": stale, "csrc_hash": csrc_hash(),
-                "launches_timed": launches, "mean_ms": mean_ms, "algorithmic_bytes": alg_bytes}
+                "launches_timed": launches, "mean_ms": mean_ms if launches else None,
+                "algorithmic_bytes": alg_bytes}
     if skip_launches:
         m_traffic, _, _ = measured_traffic(args.workload, f"seg_gather_vec_k<{F // 4}, 0, true>") \
             if not args.nodes else (None, None, None)
@@ -534,27 +535,36 @@ def run_inference(args, R):
     f32_flops = 2.0 * nodes * (2 * hidden) * out_dim
     issued = f32_flops * (6.0 if split else 1.0)
     peak = MFMA_BF16_PEAK_TFS if split else MFMA_F32_PEAK_TFS
-    ach = issued / (mean_ms * 1e-3) / 1e12 if launches else float("nan")
+    ach = issued / (mean_ms * 1e-3) / 1e12 if launches else None
     roofline = {
         "bound": "mfma",
         "kernel": ("gemm_split_k<4>" if split else "gemm_wide_k<2>") +
                   f" ({hidden}->{out_dim} projection; the bracket also holds the weight pack/split, "
                   "microseconds)",
-        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if launches else None,
         "flops_counted": "MFMA flops issued = 6 bf16 products per fp32 product" if split
         else "fp32 MFMA flops",
         "fp32_equivalent_tflops": f32_flops / (mean_ms * 1e-3) / 1e12 if launches else None,
         "fp32_equivalent_frac_of_f32_matrix_peak":
             f32_flops / (mean_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS if launches else None,
-        "traffic": None, "launches_timed": launches, "mean_ms": mean_ms,
+        "traffic": None, "launches_timed": launches, "mean_ms": mean_ms if launches else None,
         "algorithmic_flops": f32_flops, "csrc_hash": csrc_hash()}
     F = hidden
-    gl, gms = summ.get(f"segment_gather_F{F}", (0, float("nan")))
-    alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F
-    gach = alg_bytes / (gms * 1e-3) / 1e9 if gl else float("nan")
-    roofline["gather"] = {"bound": "hbm", "kernel": f"seg_gather_vec_k<{F // 4}, 0, false>, F={F}",
-                          "achieved": gach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": gach / HBM_PEAK_GBS, "launches_timed": gl, "mean_ms": gms,
+    alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F        # SURVEY 8(d), per layer
+    blocked_tag = f"segment_gather_F64x{F // 64}_blocked"
+    if blocked_tag in summ:
+        # hidden activations kept as F/64 tables of [N,64]: one layer's aggregation = F/64 launches
+        # of the 64-wide gather (bracketed together); priced on the SAME algorithmic bytes as the
+        # single 256-wide gather it replaces (the col re-reads of launches 2..4 are not counted)
+        gl, gms = summ[blocked_tag]
+        gname = f"{F // 64} x seg_gather_vec_k<16, 0, false> over column-blocked [N,64] tables, F={F}"
+    else:
+        gl, gms = summ.get(f"segment_gather_F{F}", (0, float("nan")))
+        gname = f"seg_gather_vec_k<{F // 4}, 0, false>, F={F}"
+    gach = alg_bytes / (gms * 1e-3) / 1e9 if gl else None
+    roofline["gather"] = {"bound": "hbm", "kernel": gname, "achieved": gach, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": gach / HBM_PEAK_GBS if gl else None,
+                          "launches_timed": gl, "mean_ms": gms if gl else None,
                           "algorithmic_bytes": alg_bytes}
     per_kernel = {k: {"launches": v[0], "mean_ms": v[1]} for k, v in sorted(summ.items())}
     if rank == 0:

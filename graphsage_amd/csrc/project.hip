@@ -87,6 +87,10 @@ struct GemmArgs {
   int64_t M;
   int K1, K, N1, Ncols;
   EpiArgs epi;
+  // column-blocked operands (gemm_split_k only): element (row, col) of A1/A2 resp. C1 sits at
+  // (col / 64) * blk + row * 64 + col % 64, i.e. the matrix is kept as Ncols/64 separate
+  // [M, 64] tables; 0 = plain row-major
+  int64_t a_blk, c_blk;
 };
 
 // staging registers use the native vector type: a float4 (struct) that is only copied in and
@@ -359,7 +363,8 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][TN], const GemmAr
         if (grow < a.M) {
           float v = acc[i][j][r];
           if (e.mode == MODE_DX && !second && e.row_scale) v *= e.row_scale[grow];
-          C[grow * ldc + col] = v;
+          if (a.c_blk && !second) C[(int64_t)(col >> 6) * a.c_blk + grow * 64 + (col & 63)] = v;
+          else C[grow * ldc + col] = v;
         }
       }
   }
@@ -547,7 +552,10 @@ __global__ void __launch_bounds__(256, 2) gemm_split_k(GemmArgs a, const uint16_
       int64_t grow = row0 + (f >> 3);                                                         \
       const int k = (KC) + (f & 7) * 4;                                                       \
       grow = grow < a.M ? grow : 0;      /* rows past M: zeroed when split, not here */       \
-      const float *src = (k < K1) ? a.A1 + grow * K1 + k : a.A2 + grow * K2 + (k - K1);       \
+      const int kk = k < K1 ? k : k - K1;                                                     \
+      const float *src = a.a_blk                                                              \
+          ? (k < K1 ? a.A1 : a.A2) + (int64_t)(kk >> 6) * a.a_blk + grow * 64 + (kk & 63)     \
+          : (k < K1 ? a.A1 + grow * K1 + k : a.A2 + grow * K2 + (k - K1));                    \
       ra[i] = *(const f32x4v *)src;                                                           \
     }                                                                                         \
   }
@@ -1099,7 +1107,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
                   const float *__restrict__ wt /* [16][Fo] */, int64_t N, int Fo, EpiArgs e,
-                  float *__restrict__ out, uint64_t *__restrict__ sign) {
+                  float *__restrict__ out, uint64_t *__restrict__ sign, int64_t out_blk = 0) {
   constexpr int K16_PP = 68;                   // pitch of the 16 x 64 output patch
   __shared__ __align__(16) float patches[4][16 * K16_PP];
   float *patch = patches[threadIdx.x >> 6];
@@ -1176,7 +1184,12 @@ project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
       const int rr = 4 * i + q;                       // q = lane >> 4: 4 rows per instruction
       const int64_t orow = r0 + rr;
       const float4 o = *(const float4 *)(patch + rr * K16_PP + rl * 4);
-      if (orow < N) *(float4 *)(out + orow * Fo + cb + rl * 4) = o;
+      if (orow < N) {
+        // out_blk: the output as Fo/64 separate [N,64] tables (this workgroup writes table cb/64)
+        float *dst = out_blk ? out + (int64_t)blockIdx.y * out_blk + orow * 64 + rl * 4
+                             : out + orow * Fo + cb + rl * 4;
+        *(float4 *)dst = o;
+      }
       if (sign) {
         // which outputs are positive, for the backward's ReLU'/dropout' (gsage_relu_sign_words):
         // per group of 4 rows and column block four 64-bit words, word c bit l = component c of
@@ -1567,17 +1580,25 @@ extern "C" size_t gsage_relu_sign_bytes(int64_t N, int64_t Fo) {
   return (size_t)(((N + 3) / 4) * 4 * ((Fo + 63) / 64) + 1) * sizeof(uint64_t);
 }
 
-extern "C" int gsage_project_fwd_ex(const float *agg, const float *x, const float *w_l,
-                                    const float *b_l, const float *w_r, int64_t N, int64_t Fi,
-                                    int64_t Fo, int epilogue, const uint8_t *keep_mask,
-                                    uint64_t seed, float p, float *out, float *rnorm, void *wpack,
-                                    int force_generic, uint64_t *relu_sign,
-                                    gsage_stream_t stream) {
+static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
+                            const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                            int64_t Fo, int epilogue, const uint8_t *keep_mask,
+                            uint64_t seed, float p, float *out, float *rnorm, void *wpack,
+                            int force_generic, uint64_t *relu_sign, int64_t in_blk, int64_t out_blk,
+                            gsage_stream_t stream) {
   if (N < 0 || Fi <= 0 || Fo <= 0 || !agg || !x || !w_l || !b_l || !w_r || !out || !wpack)
     return GSAGE_ERR_INVALID_ARG;
   if (epilogue < GSAGE_EPI_NONE || epilogue > GSAGE_EPI_L2NORM) return GSAGE_ERR_INVALID_ARG;
   if (epilogue == GSAGE_EPI_RELU_DROPOUT && !(p >= 0.f && p < 1.f)) return GSAGE_ERR_INVALID_ARG;
   if (Fi > 16384 || Fo > 16384) return GSAGE_ERR_UNSUPPORTED;
+  if (in_blk || out_blk) {
+    // column-blocked operands: the first-layer MFMA kernel (row-major 8-wide input) and the
+    // bf16-split GEMMs only
+    const bool first = Fi == 8 && !in_blk && Fo % 64 == 0 && epilogue != GSAGE_EPI_L2NORM;
+    const bool wide = mfma_dim(Fi) && (Fo == 128 || Fo == 256) && Fi >= 64 && wide_gemm_mode() != 0 &&
+                      (!in_blk || Fi >= 128);
+    if (force_generic != 0 || !(first || wide)) return GSAGE_ERR_UNSUPPORTED;
+  }
   if (N == 0) return GSAGE_OK;
   hipStream_t st = gs_stream(stream);
   // only the first-layer MFMA kernel leaves sign bits; the word behind them tells the backward
@@ -1614,6 +1635,7 @@ extern "C" int gsage_project_fwd_ex(const float *agg, const float *x, const floa
     GemmArgs a{};
     a.A1 = agg; a.A2 = x; a.Bp = wp; a.C1 = out; a.C2 = nullptr;
     a.M = N; a.K1 = fi; a.K = 2 * fi; a.N1 = fo; a.Ncols = fo; a.epi = e;
+    a.a_blk = in_blk; a.c_blk = out_blk;
     if (force_generic == 0 && (fo == 128 || fo == 256)) return launch_wide(fo, a, wpack, Fi, Fo, st);
     return launch_gemm_bn(fo, a, st);
   }
@@ -1624,7 +1646,7 @@ extern "C" int gsage_project_fwd_ex(const float *agg, const float *x, const floa
     int g16 = gs_grid(N, 64, 256 * 8);
     const bool relu = epilogue == GSAGE_EPI_RELU || epilogue == GSAGE_EPI_RELU_DROPOUT;
     hipLaunchKernelGGL(project_fwd_k16_k, dim3(g16, fo / 64), dim3(256), 0, st, agg, x, wp, N, fo, e,
-                       out, relu ? relu_sign : nullptr);
+                       out, relu ? relu_sign : nullptr, out_blk);
     sign_written = relu;
   } else if (2 * Fi <= 16 && (Fo <= 64 || (Fo % 64 == 0 && epilogue != GSAGE_EPI_L2NORM)))
     hipLaunchKernelGGL((project_fwd_smallk_k<16>), dim3(grid, (fo + 63) / 64), dim3(256), 0, st, agg,
@@ -1638,6 +1660,41 @@ extern "C" int gsage_project_fwd_ex(const float *agg, const float *x, const floa
     GSAGE_CHECK_LAUNCH();
   }
   return GSAGE_OK;
+}
+
+extern "C" int gsage_project_fwd_ex(const float *agg, const float *x, const float *w_l,
+                                    const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                                    int64_t Fo, int epilogue, const uint8_t *keep_mask,
+                                    uint64_t seed, float p, float *out, float *rnorm, void *wpack,
+                                    int force_generic, uint64_t *relu_sign,
+                                    gsage_stream_t stream) {
+  return project_fwd_impl(agg, x, w_l, b_l, w_r, N, Fi, Fo, epilogue, keep_mask, seed, p, out, rnorm,
+                          wpack, force_generic, relu_sign, 0, 0, stream);
+}
+
+extern "C" int gsage_project_fwd_blocked_supported(int64_t Fi, int64_t Fo, int in_blocked,
+                                                   int out_blocked, int epilogue) {
+  if (!in_blocked && !out_blocked) return 1;
+  if (epilogue == GSAGE_EPI_RELU_DROPOUT) return 0;
+  const bool first = Fi == 8 && !in_blocked && Fo % 64 == 0 && epilogue != GSAGE_EPI_L2NORM;
+  const bool wide = mfma_dim(Fi) && (Fo == 128 || Fo == 256) && wide_gemm_mode() != 0 &&
+                    (!in_blocked || Fi >= 128);
+  return first || wide ? 1 : 0;
+}
+
+extern "C" int gsage_project_fwd_blocked(const float *agg, const float *x, const float *w_l,
+                                         const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                                         int64_t Fo, int epilogue, float *out, float *rnorm,
+                                         void *wpack, int in_blocked, int out_blocked,
+                                         gsage_stream_t stream) {
+  if (epilogue == GSAGE_EPI_RELU_DROPOUT) return GSAGE_ERR_UNSUPPORTED;   // inference layouts
+  if (!gsage_project_fwd_blocked_supported(Fi, Fo, in_blocked, out_blocked, epilogue))
+    return GSAGE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)agg | (uintptr_t)x | (uintptr_t)out | (uintptr_t)b_l) & 15) != 0)
+    return GSAGE_ERR_UNSUPPORTED;       // the tile kernels need 16-byte aligned operands
+  return project_fwd_impl(agg, x, w_l, b_l, w_r, N, Fi, Fo, epilogue, nullptr, 0, 0.f, out, rnorm,
+                          wpack, 0, nullptr, in_blocked ? N * 64 : 0, out_blocked ? N * 64 : 0,
+                          stream);
 }
 
 extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *w_l,

@@ -17,7 +17,12 @@ import torch.nn.functional as F
 
 from . import _lib
 from .graph import GraphCSR, default_cache
+from . import ops
 from .ops import SAGELayerFunction, aggregate_mean
+
+
+def _f32(x: torch.Tensor) -> torch.Tensor:
+    return x.contiguous()
 
 
 _VEC_WIDTHS = (4, 8, 16, 32, 64, 128, 256)
@@ -126,6 +131,8 @@ class GraphSAGE(nn.Module):
         dropout masks instead of drawing them in the kernel (parity tests).
         """
         graph = default_cache().get(edge_index, x.size(0))
+        if self._blocked_inference_applies(x):
+            return self._forward_blocked(x, graph)
         p = float(self.dropout_rate)
         training = self.training and p > 0.0
         for i, conv in enumerate(self.convs[:-1]):
@@ -140,6 +147,50 @@ class GraphSAGE(nn.Module):
         epi = _lib.EPI_L2NORM if self.normalize_output else _lib.EPI_NONE
         return self.convs[-1].run(x, graph, epi, 0.0, 0, None, self._force_generic,
                                   input_layer=len(self.convs) == 1)
+
+    # ---- wide models without autograd: hidden activations kept column-blocked (ops.py)
+    def _blocked_inference_applies(self, x: torch.Tensor) -> bool:
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        if self.training and float(self.dropout_rate) > 0.0:
+            return False
+        h = self.hidden_channels
+        if self._force_generic or len(self.convs) < 2 or h not in (128, 256) or not x.is_cuda:
+            return False
+        if vector_width(x.size(1)) != 8 or x.dtype != torch.float32:
+            return False
+        if x.size(0) * h * 4 < ops.BLOCKED_MIN_BYTES:
+            return False
+        lib = _lib.load()
+        last = self.convs[-1]
+        epi = _lib.EPI_L2NORM if self.normalize_output else _lib.EPI_NONE
+        ok = lib.gsage_project_fwd_blocked_supported(8, h, 0, 1, _lib.EPI_RELU)
+        ok = ok and all(lib.gsage_project_fwd_blocked_supported(h, h, 1, 1, _lib.EPI_RELU)
+                        for _ in self.convs[1:-1])
+        return bool(ok and lib.gsage_project_fwd_blocked_supported(h, last.out_channels, 1, 0, epi))
+
+    def _forward_blocked(self, x: torch.Tensor, graph: GraphCSR) -> torch.Tensor:
+        """Same arithmetic as the plain path, layer by layer; only the memory layout of the
+        hidden activations differs (F/64 tables of [N,64]), so every gather runs on a table a
+        quarter of the size."""
+        first = self.convs[0]
+        x8 = default_cache().padded(_f32(x), 8, keep=True)
+        pad = 8 - first.in_channels
+        w_l, w_r = F.pad(first.lin_l.weight, (0, pad)), F.pad(first.lin_r.weight, (0, pad))
+        agg = ops.aggregate_mean(graph, x8)
+        h, _ = ops.project_fwd_blocked(agg, x8, w_l, first.lin_l.bias, w_r, _lib.EPI_RELU, False, True)
+        del agg
+        for conv in self.convs[1:-1]:
+            agg = ops.aggregate_mean_blocked(graph, h)
+            h, _ = ops.project_fwd_blocked(agg, h, conv.lin_l.weight, conv.lin_l.bias,
+                                           conv.lin_r.weight, _lib.EPI_RELU, True, True)
+            del agg
+        last = self.convs[-1]
+        epi = _lib.EPI_L2NORM if self.normalize_output else _lib.EPI_NONE
+        agg = ops.aggregate_mean_blocked(graph, h)
+        out, _ = ops.project_fwd_blocked(agg, h, last.lin_l.weight, last.lin_l.bias,
+                                         last.lin_r.weight, epi, True, False)
+        return out
 
     def get_embedding_dim(self) -> int:
         return self.out_channels

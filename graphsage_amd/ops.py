@@ -118,6 +118,60 @@ def aggregate_mean(graph: GraphCSR, x: torch.Tensor) -> torch.Tensor:
                           long_rows=graph.long_rows, n_long=graph.n_long[0:1])
 
 
+# ------------------------------------------------ column-blocked activations (wide inference)
+# A blocked [N, F] activation is F/64 separate [N, 64] tables: tensor shape [F/64, N, 64].  The
+# 256-wide gather over one 10 GB table runs 15 % below the same bytes gathered from 2.56 GB
+# tables, so in no-grad forwards of the 128/256-wide models the hidden layers hand their output
+# on in this form (GraphSAGE.forward decides; GSAGE_BLOCKED_MIN_BYTES sets the table size from
+# which it does, default 4 GiB; the layouts agree to fp32 rounding: the 64-wide gather adds the
+# neighbours of a row in another order than the 256-wide one).
+BLOCKED_MIN_BYTES = int(os.environ.get("GSAGE_BLOCKED_MIN_BYTES", str(4 << 30)))
+
+
+def aggregate_mean_blocked(graph: GraphCSR, xb: torch.Tensor) -> torch.Tensor:
+    """Mean aggregation of a blocked activation [F/64, N, 64] -> blocked [F/64, N, 64]."""
+    global _timer
+    nb = xb.size(0)
+    out = torch.empty_like(xb)
+    timer, ev = _timer, None
+    if timer is not None and timer.enabled:
+        ev = timer.bracket(f"segment_gather_F64x{nb}_blocked")
+        ev[0].record()
+    _timer = None                      # one bracket around the F/64 launches, not one each
+    try:
+        for b in range(nb):
+            segment_gather(graph.rowptr, graph.col, xb[b], row_scale=graph.inv_deg, out=out[b],
+                           long_rows=graph.long_rows, n_long=graph.n_long[0:1])
+    finally:
+        _timer = timer
+    if ev:
+        ev[1].record()
+    return out
+
+
+def project_fwd_blocked(agg, x, w_l, b_l, w_r, epilogue, in_blocked: bool, out_blocked: bool):
+    """K3 forward with column-blocked operands (gsage_project_fwd_blocked) -> (out, rnorm)."""
+    lib = _lib.load()
+    Fo, Fi = w_l.shape
+    N = x.size(1) if in_blocked else x.size(0)
+    dev = x.device
+    with torch.cuda.device(dev):
+        out = torch.empty((Fo // 64, N, 64) if out_blocked else (N, Fo), dtype=torch.float32, device=dev)
+        rnorm = torch.empty(N, dtype=torch.float32, device=dev) if epilogue == EPI_L2NORM else None
+        wpack = torch.empty(lib.gsage_project_workspace_bytes(Fi, Fo), dtype=torch.uint8, device=dev)
+        ev = _timer.bracket(f"project_fwd_{Fi}x{Fo}") if _timer is not None and _timer.enabled else None
+        if ev:
+            ev[0].record()
+        rc = lib.gsage_project_fwd_blocked(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(),
+                                           b_l.data_ptr(), w_r.data_ptr(), N, Fi, Fo, int(epilogue),
+                                           out.data_ptr(), _lib.ptr(rnorm), wpack.data_ptr(),
+                                           int(in_blocked), int(out_blocked), _lib.stream_handle())
+        if ev:
+            ev[1].record()
+    _lib.check(rc, "gsage_project_fwd_blocked")
+    return out, rnorm
+
+
 def aggregate_mean_bwd(graph: GraphCSR, grad_agg: torch.Tensor, prescaled: bool = False,
                        add_to: Optional[torch.Tensor] = None,
                        nz_mask: Optional[torch.Tensor] = None,

@@ -211,6 +211,23 @@ int gsage_project_bwd_rows(const float *grad_out, const float *out, const float 
                            float *grad_w_r, void *ws, size_t ws_bytes, const int32_t *live_rows,
                            const int32_t *n_live, int64_t live_cap, gsage_stream_t stream);
 
+/* K3 forward on COLUMN-BLOCKED activations (inference of the wide models, encoder.py:181-185 with
+ * hidden_dim 128/256): a blocked [N,F] matrix is F/64 separate row-major [N,64] tables laid end
+ * to end (element (r,c) at (c/64)*N*64 + r*64 + c%64).  The 256-wide gather over one 10 GB table
+ * runs 15 % below the same bytes gathered from 2.56 GB tables, so a hidden layer
+ * writes its output blocked, the next layer's aggregation is F/64 gathers of width 64
+ * (gsage_segment_gather on each table), and its projection reads both operands blocked.
+ * in_blocked / out_blocked say which side is blocked (agg and x share the input layout); same
+ * arithmetic as gsage_project_fwd (the GEMM gives the same bits for the same inputs).  Eval epilogues only
+ * (NONE, RELU, L2NORM); gsage_project_fwd_blocked_supported says which shapes have a kernel
+ * (8 -> 64k row-major in / blocked out; 128|256 -> 128|256 on the bf16-split GEMM). */
+int gsage_project_fwd_blocked_supported(int64_t Fi, int64_t Fo, int in_blocked, int out_blocked,
+                                        int epilogue);
+int gsage_project_fwd_blocked(const float *agg, const float *x, const float *w_l,
+                              const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                              int64_t Fo, int epilogue, float *out, float *rnorm, void *wpack,
+                              int in_blocked, int out_blocked, gsage_stream_t stream);
+
 /* ---------------------------------------------------------- K4 / K5: skip-gram loss
  * K4 replaces SkipGramLoss.forward / forward_with_details (src/model/loss.py:97-136,
  * 161-193): three row gathers, B + B*K dots, x scale, logsigmoid means, and the

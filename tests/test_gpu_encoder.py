@@ -111,3 +111,43 @@ def test_full_size_c5_encode_properties():
     h = torch.nn.functional.normalize(h, dim=1)
     assert float((emb[iso].double() - h).abs().max()) <= 2e-6
     assert bool(torch.isfinite(chk).all())
+
+
+@pytest.mark.parametrize("hidden,out,layers,n", [(256, 256, 3, 5000), (128, 128, 2, 7001), (256, 128, 4, 3000),
+                                                 (128, 256, 3, 2500)])
+def test_blocked_inference_layout_matches_plain_layout_and_oracle(hidden, out, layers, n):
+    """Wide models without autograd keep their hidden activations column-blocked ([F/64, N, 64])
+    from a table size on (ops.BLOCKED_MIN_BYTES).  Same arithmetic; the neighbour sums are taken
+    by the 64-wide gather instead of the 128/256-wide one, whose lanes add the neighbours in a
+    different order, so the two layouts agree to fp32 rounding, each is repeatable bit for bit,
+    and both match the oracle."""
+    from graphsage_amd import GraphSAGE, ops
+    from graphsage_amd.synth import memory_features, powerlaw_graph
+    ei = powerlaw_graph(n, 14, seed=3, max_degree=2000)
+    x = memory_features(n, seed=3)
+    torch.manual_seed(2)
+    ref = O.OracleGraphSAGE(7, hidden, out, layers, 0.0).eval()
+    m = GraphSAGE(7, hidden, out, layers, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda().eval()
+    xg, eg = x.cuda(), ei.cuda()
+    saved = ops.BLOCKED_MIN_BYTES
+    try:
+        with torch.no_grad():
+            ops.BLOCKED_MIN_BYTES = 1 << 60
+            assert not m._blocked_inference_applies(xg)
+            plain = m(xg, eg)
+            ops.BLOCKED_MIN_BYTES = 0
+            assert m._blocked_inference_applies(xg)
+            blocked = m(xg, eg)
+            assert torch.equal(blocked, m(xg, eg))           # deterministic
+        assert not m._blocked_inference_applies(xg)          # autograd on: the plain path
+        m.train()
+    finally:
+        ops.BLOCKED_MIN_BYTES = saved
+    assert blocked.shape == (n, out)
+    assert_close(blocked, plain, what="blocked vs plain layout")
+    with torch.no_grad():
+        want = ref(x, ei)
+    assert_close(blocked, want, what="blocked vs oracle")
+    assert_close(plain, want, what="plain vs oracle")
