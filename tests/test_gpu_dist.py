@@ -28,3 +28,4 @@ def test_two_ranks_on_one_gpu_match_single_process():
     for a, b in zip(d["losses"], d["ref_losses"]):
         assert a == pytest.approx(b, rel=1e-5)
     assert d["max_param_diff"] <= 1e-5
+    assert d["live_rows_used"] == 6          # 3 sharded steps + 3 whole-batch steps on rank 0

@@ -19,7 +19,8 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
-    n, B, K, steps = 5000, 4099, 5, 3                    # 4099: uneven shards
+    n, B, K, steps = 20000, 4099, 5, 3      # 4099: uneven shards; n large enough for the
+    # touched-row hand-over to be taken (ops.live_rows_worthwhile) on shards and whole batch alike
     ei = powerlaw_graph(n, 12, seed=3, device=dev)
     x = memory_features(n, seed=3, device=dev)
     batches = [cooccurrence_batch(ei, n, B, K, seed=10 + s) for s in range(steps)]
@@ -42,8 +43,10 @@ def main():
         ref_losses = [float(ref.step(*b)[0]) for b in batches]
         worst = max(float((a.detach() - b.detach()).abs().max())
                     for a, b in zip(model.parameters(), ref_model.parameters()))
+        from graphsage_amd import ops
         print(json.dumps({"world": world, "losses": losses, "ref_losses": ref_losses,
-                          "max_param_diff": worst}), flush=True)
+                          "max_param_diff": worst, "live_rows_used": ops.LIVE_STATS["used"]}),
+              flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
