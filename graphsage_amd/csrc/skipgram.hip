@@ -450,12 +450,20 @@ rows_zero_k(const int *__restrict__ rows, const int *__restrict__ n_rows, int64_
   }
 }
 
+// Grid of the (grid-stride) forward kernels: never more workgroups than the chip holds at once.
+// 256 CUs x 6 workgroups (the vector kernel runs 7 waves per SIMD): with 2048 workgroups the last
+// 256 started only when the first 1792 had finished their 32 trips, i.e. the kernel ran two
+// rounds where 1.14 would do: 0.56 -> 0.43 ms at C4 (5 per CU: 0.48, 7 per CU: 0.62).
+#ifndef SG_GRID_CAP
+#define SG_GRID_CAP (256 * 6)
+#endif
 int sg_blocks(int64_t B, int pairs_per_block) {
   int64_t nb = (B + pairs_per_block - 1) / pairs_per_block;
   if (nb < 1) nb = 1;
-  if (nb > SG_MAX_BLOCKS) nb = SG_MAX_BLOCKS;
+  if (nb > SG_GRID_CAP) nb = SG_GRID_CAP;
   return (int)nb;
 }
+static_assert(SG_GRID_CAP <= SG_MAX_BLOCKS, "partials are sized for SG_MAX_BLOCKS workgroups");
 
 }  // namespace
 
