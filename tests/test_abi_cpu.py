@@ -71,3 +71,36 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h")):
                 assert "oracle" not in open(os.path.join(dirpath, f)).read(), f
+
+
+def test_round2_entry_points_validate_before_touching_the_device():
+    from graphsage_amd import _lib
+    lib = _lib.load()
+    # touched rows / zero rows
+    assert lib.gsage_touched_rows_workspace_bytes(0) == 0
+    assert lib.gsage_touched_rows_workspace_bytes(10_000_000) >= 10_000_000      # a flag byte per row
+    assert lib.gsage_touched_rows(None, None, None, 8, 5, 100, None, None, 10, None, None, 0, None) == -1
+    assert lib.gsage_zero_rows(None, None, 10, 64, None, None) == -1
+    # the row-list backward exists for 64 -> 64 only; other shapes say so instead of guessing
+    assert lib.gsage_project_bwd_rows_supported(64, 64) == 1
+    assert lib.gsage_project_bwd_rows_supported(128, 128) == 0 and lib.gsage_project_bwd_rows_supported(8, 64) == 0
+    assert lib.gsage_project_bwd_rows(None, None, None, None, None, None, None, None, 10, 128, 128, 3, 0.0,
+                                      None, None, None, None, None, None, 0, None, None, 0, None) == -2
+    # the add_to mask is not a hint: widths that cannot honour it are refused
+    assert lib.gsage_segment_gather_live(None, None, None, None, None, None, 10, 64, None, None, None,
+                                         None, None) == -1
+    # column-blocked projection: which shapes have a kernel
+    sup = lib.gsage_project_fwd_blocked_supported
+    assert sup(8, 256, 0, 1, _lib.EPI_RELU) == 1 and sup(256, 256, 1, 1, _lib.EPI_RELU) == 1
+    assert sup(256, 256, 1, 0, _lib.EPI_L2NORM) == 1 and sup(128, 256, 1, 0, _lib.EPI_NONE) == 1
+    assert sup(8, 256, 0, 1, _lib.EPI_L2NORM) == 0          # first layer: no blocked L2-norm form
+    assert sup(64, 64, 1, 1, _lib.EPI_RELU) == 0 and sup(256, 256, 1, 1, _lib.EPI_RELU_DROPOUT) == 0
+    assert sup(7, 100, 0, 0, _lib.EPI_NONE) == 1            # nothing blocked: the plain entry point's job
+    assert lib.gsage_project_fwd_blocked(None, None, None, None, None, 10, 64, 64, 1, None, None, None,
+                                         1, 1, None) == -2
+    # feeder kernel and the no-alloc loss
+    assert lib.gsage_alias_sample(None, None, 10, 5, 0, 0, None, None) == -1
+    assert lib.gsage_skipgram_noalloc_max_pairs() == 1 << 24
+    assert lib.gsage_skipgram_fwd_noalloc(None, 4, 64, None, None, None, (1 << 24) + 1, 5, 5.0, 8.0, 40.0,
+                                          None, None, None) == -5
+    assert b"no-alloc" in lib.gsage_error_string(-5)
