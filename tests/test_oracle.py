@@ -212,3 +212,40 @@ def test_two_layer_forward_against_exact_rational_arithmetic():
     norms = want_pre.norm(dim=1, keepdim=True).clamp(min=1e-12)
     assert torch.allclose(got, want_pre / norms, rtol=1e-6, atol=1e-6)
     assert torch.equal(got[8] != 0, (want_pre[8] != 0))      # the isolated node still gets b_l + W_r x
+
+
+def test_oracle_layer_equals_the_sparse_matrix_form_in_scipy():
+    """A second, independent derivation of the SAGEConv arithmetic (PyG's documented formula
+    x_i' = W_r x_i + W_l mean_{j in N(i)} x_j + b): the mean as a row-normalised sparse adjacency
+    product D^-1 A x built with scipy.sparse (coo -> csr sums duplicate edges, so multiplicities
+    count; a row without in-edges stays zero), forward and parameter gradients in float64 against
+    the oracle's index_select / scatter_add restatement.  The reference holds no numbers for this
+    layer (parity unpinned); this pins the two derivations to each other."""
+    import numpy as np
+    import scipy.sparse as sp
+    g = torch.Generator().manual_seed(5)
+    n, e, fi, fo = 300, 2500, 7, 16
+    ei = torch.randint(0, n, (2, e), generator=g)          # duplicates and self-loops occur
+    ei[1, :40] = 7                                          # a hub target
+    ei = ei[:, ei[1] != 11]                                 # node 11 has no in-edges
+    x = torch.randn(n, fi, generator=g, dtype=torch.float64)
+    conv = O.OracleSAGEConv(fi, fo).double()
+    out = conv(x.clone().requires_grad_(False), ei)
+    A = sp.coo_matrix((np.ones(ei.size(1)), (ei[1].numpy(), ei[0].numpy())), shape=(n, n)).tocsr()
+    deg = np.maximum(np.asarray(A.sum(1)).ravel(), 1.0)
+    agg = sp.diags(1.0 / deg) @ A @ x.numpy()
+    assert np.abs(agg[11]).max() == 0.0
+    w_l, b_l, w_r = (conv.lin_l.weight.detach().numpy(), conv.lin_l.bias.detach().numpy(),
+                     conv.lin_r.weight.detach().numpy())
+    want = agg @ w_l.T + b_l + x.numpy() @ w_r.T
+    assert np.abs(out.detach().numpy() - want).max() <= 1e-12
+    # gradients of sum(out * P): dW_l = P^T agg, dW_r = P^T x, db = colsum P, dx = W_r^T P + A^T D^-1 P W_l
+    P = torch.randn(n, fo, generator=g, dtype=torch.float64)
+    xg = x.clone().requires_grad_(True)
+    (conv(xg, ei) * P).sum().backward()
+    p = P.numpy()
+    assert np.abs(conv.lin_l.weight.grad.numpy() - p.T @ agg).max() <= 1e-10
+    assert np.abs(conv.lin_r.weight.grad.numpy() - p.T @ x.numpy()).max() <= 1e-10
+    assert np.abs(conv.lin_l.bias.grad.numpy() - p.sum(0)).max() <= 1e-10
+    dx = p @ w_r + (A.T @ (sp.diags(1.0 / deg) @ (p @ w_l)))
+    assert np.abs(xg.grad.numpy() - dx).max() <= 1e-10
