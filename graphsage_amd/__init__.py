@@ -9,7 +9,7 @@ from .sampler import DegreeBiasedNegativeSampler, UniformNegativeSampler
 from .encoder import StructuralEncoder, model_from_checkpoint
 from .walks import RandomWalkGenerator, CooccurrencePairSampler, estimate_pair_count
 from .trainer import (GraphSAGETrainer, BatchGenerator, StreamingBatchGenerator, Batch,
-                      split_pairs_train_val)
+                      split_pairs_train_val, train_graphsage)
 from .datafiles import load_training_data, save_training_data, load_walks
 
 __all__ = ["GraphSAGE", "SAGEConv", "create_model", "SkipGramLoss", "create_loss", "GraphCSR",
@@ -17,5 +17,5 @@ __all__ = ["GraphSAGE", "SAGEConv", "create_model", "SkipGramLoss", "create_loss
            "UniformNegativeSampler", "GraphSAGETrainer", "BatchGenerator", "Batch",
            "split_pairs_train_val", "StructuralEncoder", "model_from_checkpoint",
            "RandomWalkGenerator", "CooccurrencePairSampler", "estimate_pair_count",
-           "StreamingBatchGenerator", "load_training_data", "save_training_data", "load_walks"]
+           "StreamingBatchGenerator", "train_graphsage", "load_training_data", "save_training_data", "load_walks"]
 __version__ = "0.1.0"

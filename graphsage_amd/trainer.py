@@ -326,3 +326,47 @@ class StreamingBatchGenerator:
             if neg.device != self.device:
                 neg = neg.to(self.device)
             yield Batch(t, c, neg, size)
+
+
+def train_graphsage(dataset, walks, config: Dict[str, Any], device=None):
+    """Counterpart of ``train_graphsage`` (``trainer.py:408-486``), "the recommended entry point
+    for training": pairs out of the walks, degree-biased negative sampler, model from the config,
+    trainer, ``train(epochs)`` -> ``(trained_model, embeddings)``.
+
+    ``dataset``: anything with ``get_data(device=)`` returning an object with ``x``,
+    ``edge_index`` and ``num_nodes`` (the reference's ``GraphSAGEDataset``), or a plain
+    ``(features, edge_index)`` pair.  ``walks``: the reference's list of lists, or the
+    ``(walks, lengths)`` tensors of :class:`RandomWalkGenerator`; the pairs are extracted on the
+    device in the reference's order either way."""
+    from .graphsage import GraphSAGE
+    from .sampler import DegreeBiasedNegativeSampler
+    from .walks import CooccurrencePairSampler
+    device = torch.device(device) if device is not None else torch.device("cuda")
+    assert device.type == "cuda", "GPU required for training"
+    if hasattr(dataset, "get_data"):
+        data = dataset.get_data(device=device)
+        features, edge_index, num_nodes = data.x, data.edge_index, int(data.num_nodes)
+    else:
+        features, edge_index = dataset
+        features, edge_index = features.to(device), edge_index.to(device)
+        num_nodes = int(features.size(0))
+    window = config.get("walks", {}).get("context_window", 10)
+    if isinstance(walks, (tuple, list)) and len(walks) == 2 and torch.is_tensor(walks[0]):
+        wt, wl = walks[0].to(device, torch.int32), walks[1].to(device, torch.int32)
+    else:
+        L = max((len(w) for w in walks), default=1)
+        wl = torch.tensor([len(w) for w in walks], dtype=torch.int32, device=device)
+        wt = torch.tensor([list(w) + [-1] * (L - len(w)) for w in walks], dtype=torch.int32,
+                          device=device).reshape(len(walks), L)
+    pairs = CooccurrencePairSampler(window).extract_pairs_tensor(wt.contiguous(), wl.contiguous())
+    neg_sampler = DegreeBiasedNegativeSampler(edge_index, num_nodes,
+                                              exponent=config.get("negatives", {}).get("exponent", 0.75),
+                                              device=device)
+    mc = config.get("model", {})
+    model = GraphSAGE(in_channels=config.get("features", {}).get("dimensions", 7),
+                      hidden_channels=mc.get("hidden_dim", 64), out_channels=mc.get("output_dim", 64),
+                      num_layers=mc.get("num_layers", 2), dropout=mc.get("dropout", 0.3),
+                      normalize_output=mc.get("normalize_output", True)).to(device)
+    trainer = GraphSAGETrainer(model, features, edge_index, pairs, neg_sampler, config)
+    trainer.train(num_epochs=config.get("training", {}).get("epochs", 100))
+    return model, trainer.get_embeddings()

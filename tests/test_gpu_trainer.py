@@ -244,3 +244,41 @@ def test_captured_step_survives_cache_churn_and_refuses_modified_inputs():
                 step.step_captured(t[:bs].cuda(), c[:bs].cuda(), negs[0])
     for pa, pb in zip(*results):
         assert_close(pa, pb, rtol=1e-5, floor=2e-6)
+
+
+def test_train_graphsage_entry_point():
+    """trainer.py:408-486 ("the recommended entry point"): dataset + walks + config in, trained
+    model and unit-norm embeddings out; the loss goes down and linked nodes end up closer than
+    random ones."""
+    from graphsage_amd import RandomWalkGenerator, train_graphsage
+    from graphsage_amd.synth import memory_features, powerlaw_graph
+    n = 3000
+    ei = powerlaw_graph(n, 8, seed=5).cuda()
+    x = memory_features(n, seed=5).cuda()
+
+    class Data:                                   # the reference's dataset protocol
+        def get_data(self, device=None):
+            class D:
+                pass
+            d = D()
+            d.x, d.edge_index, d.num_nodes = x.to(device), ei.to(device), n
+            return d
+
+    walks = RandomWalkGenerator(ei, n, walk_length=10, walks_per_node=2, seed=3).generate_all_walks()
+    cfg = {"features": {"dimensions": 7}, "model": {"hidden_dim": 64, "output_dim": 64, "num_layers": 2,
+                                                    "dropout": 0.1},
+           "walks": {"context_window": 3}, "negatives": {"per_positive": 5, "exponent": 0.75},
+           "training": {"epochs": 4, "batch_size": 4096, "learning_rate": 0.01,
+                        "early_stopping_patience": 10}}
+    torch.manual_seed(0)
+    model, emb = train_graphsage(Data(), walks, cfg, device="cuda")
+    assert emb.shape == (n, 64) and torch.allclose(emb.norm(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
+    src, dst = ei[0, :5000], ei[1, :5000]
+    linked = (emb[src] * emb[dst]).sum(1).mean()
+    rnd = (emb[src] * emb[torch.randint(0, n, (5000,), device="cuda")]).sum(1).mean()
+    assert float(linked - rnd) > 0.02
+    # the list-of-lists form of the walks and a plain (features, edge_index) pair work too
+    lists = RandomWalkGenerator.to_lists(*walks)[:500]
+    cfg["training"]["epochs"] = 1
+    _, emb2 = train_graphsage((x, ei), lists, cfg, device="cuda")
+    assert emb2.shape == (n, 64)
