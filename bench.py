@@ -581,7 +581,7 @@ def run_inference(args, R):
             "dtype": "f32 (wide GEMMs: bf16 MFMA on 3-way split fp32 operands, fp32 accumulate)"
             if split else "f32", "data": "synthetic",
             "config": {"workload": desc, "nodes": nodes, "edges": E,
-                       "model": f"7->{hidden}->{hidden}->{out_dim}, eval, no_grad, L2-normalised",
+                       "layers": f"7->{hidden}->{hidden}->{out_dim}, eval, no_grad, L2-normalised",
                        "parallelism": "replicas only (inference does not shard)" if world > 1
                        else "single GPU", "unit_norm_rows": unit,
                        "protocol": "scripts/benchmark_latency.py:66-105"},
