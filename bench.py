@@ -527,28 +527,49 @@ def run_inference(args, R):
     ms = elapsed / args.steps * 1e3
     summ = timer.summary()
 
-    # the MFMA-bound kernel: the 256 -> 256 projections (layers 2 and 3), gemm_split_k<4>:
-    # [agg|x] (N x 512) . [W_l|W_r]^T (512 x 256) on the bf16 matrix pipe, each fp32 product
-    # as six exact bf16 products
-    split = os.environ.get("GSAGE_WIDE_GEMM", "")[:1] != "f"
+    # the 256 -> 256 projections (layers 2 and 3): [agg|x] (N x 512) . [W_l|W_r]^T (512 x 256) on
+    # the 16-bit matrix pipe with every fp32 operand split exactly: gemm_half_k<4>
+    # (two fp16 parts, three products per fp32 product) for 256-column tiles with K >= 256,
+    # gemm_split_k (three bf16 parts, six products) otherwise; GSAGE_WIDE_GEMM forces a family
+    forced = os.environ.get("GSAGE_WIDE_GEMM", "")[:1]
+    family = {"f": "f32", "s": "bf16x3", "h": "fp16x2"}.get(
+        forced, "fp16x2" if out_dim == 256 and 2 * hidden >= 256 else "bf16x3")
+    products = {"f32": 1.0, "bf16x3": 6.0, "fp16x2": 3.0}[family]
+    kname = {"f32": "gemm_wide_k<2>", "bf16x3": "gemm_split_k<4>", "fp16x2": "gemm_half_k<4>"}[family]
     launches, mean_ms = summ.get(f"project_fwd_{hidden}x{out_dim}", (0, float("nan")))
     f32_flops = 2.0 * nodes * (2 * hidden) * out_dim
-    issued = f32_flops * (6.0 if split else 1.0)
-    peak = MFMA_BF16_PEAK_TFS if split else MFMA_F32_PEAK_TFS
+    issued = f32_flops * products
+    peak = MFMA_F32_PEAK_TFS if family == "f32" else MFMA_BF16_PEAK_TFS
     ach = issued / (mean_ms * 1e-3) / 1e12 if launches else None
-    roofline = {
-        "bound": "mfma",
-        "kernel": ("gemm_split_k<4>" if split else "gemm_wide_k<2>") +
-                  f" ({hidden}->{out_dim} projection; the bracket also holds the weight pack/split, "
-                  "microseconds)",
-        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if launches else None,
-        "flops_counted": "MFMA flops issued = 6 bf16 products per fp32 product" if split
-        else "fp32 MFMA flops",
-        "fp32_equivalent_tflops": f32_flops / (mean_ms * 1e-3) / 1e12 if launches else None,
-        "fp32_equivalent_frac_of_f32_matrix_peak":
-            f32_flops / (mean_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS if launches else None,
+    # its streams: agg and x read once, out written once, fp32 (the 0.5 MB of weights stay in L2)
+    gemm_bytes = 4.0 * nodes * (2 * hidden + out_dim)
+    gbs = gemm_bytes / (mean_ms * 1e-3) / 1e9 if launches else None
+    mfma = {"achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if launches else None,
+            "flops_counted": f"MFMA flops issued = {products:g} products per fp32 product",
+            "fp32_equivalent_tflops": f32_flops / (mean_ms * 1e-3) / 1e12 if launches else None,
+            "fp32_equivalent_frac_of_f32_matrix_peak":
+                f32_flops / (mean_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS if launches else None,
+            "algorithmic_flops": f32_flops}
+    hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": gbs / HBM_PEAK_GBS if launches else None, "algorithmic_bytes": gemm_bytes}
+    # the bound is the larger of the two floors (flops / matrix peak against bytes / HBM peak): the
+    # fp32 and bf16x3 kernels are matrix-bound; with three products the streams weigh more
+    mfma_floor = issued / (peak * 1e12)
+    hbm_floor = gemm_bytes / (HBM_PEAK_GBS * 1e9)
+    bound = "mfma" if mfma_floor >= hbm_floor else "hbm"
+    roofline = dict(mfma if bound == "mfma" else hbm)
+    roofline.update({
+        "bound": bound,
+        "kernel": f"{kname} ({hidden}->{out_dim} projection; the bracket also holds the weight "
+                  "pack/split, microseconds)",
+        "floors_ms": {"mfma": mfma_floor * 1e3, "hbm": hbm_floor * 1e3},
+        "other_bound": hbm if bound == "mfma" else mfma,
         "traffic": None, "launches_timed": launches, "mean_ms": mean_ms if launches else None,
-        "algorithmic_flops": f32_flops, "csrc_hash": csrc_hash()}
+        "csrc_hash": csrc_hash()})
+    dtype = {"f32": "f32",
+             "bf16x3": "f32 (wide GEMMs: bf16 MFMA on 3-way split fp32 operands, fp32 accumulate)",
+             "fp16x2": "f32 (wide GEMMs: fp16 MFMA on 2-way split, range-scaled fp32 operands, fp32 "
+                       "accumulate; tiles outside the range on bf16 3-way split)"}[family]
     F = hidden
     alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F        # SURVEY 8(d), per layer
     blocked_tag = f"segment_gather_F64x{F // 64}_blocked"
@@ -578,8 +599,7 @@ def run_inference(args, R):
             "ranks_seen": seen, "backend": R.backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (wide GEMMs: bf16 MFMA on 3-way split fp32 operands, fp32 accumulate)"
-            if split else "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": desc, "nodes": nodes, "edges": E,
                        "layers": f"7->{hidden}->{hidden}->{out_dim}, eval, no_grad, L2-normalised",
                        "parallelism": "replicas only (inference does not shard)" if world > 1

@@ -47,6 +47,9 @@ SIGNATURES = {
     "gsage_project_fwd_blocked_supported": (C.c_int, [_i64, _i64, C.c_int, C.c_int, C.c_int]),
     "gsage_project_fwd_blocked": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int, _p, _p,
                                             _p, C.c_int, C.c_int, _p]),
+    "gsage_project_fwd_range_supported": (C.c_int, [_i64, _i64, C.c_int]),
+    "gsage_project_fwd_range": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int, _p, _p,
+                                          _p, C.c_int, C.c_int, _p, _p, _p]),
     "gsage_project_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "gsage_project_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int,
                                     C.c_float, _p, _p, _p, _p, _p, _p, _p, _sz, C.c_int, _p]),

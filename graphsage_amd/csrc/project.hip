@@ -48,7 +48,16 @@ struct EpiArgs {
   float inv_keep;
   float *rnorm;
   const float *row_scale;  // dX: scale of destination 1
+  unsigned *amax_out;      // nullable: max |out| as float bits (atomicMax), for the next layer's fp16 scaling
 };
+
+// largest |value| a wave stored -> *dst (float bits compare like unsigned integers; NaN above Inf).
+// One L2 read per wave, an atomic only from a wave that raises the maximum.
+__device__ __forceinline__ void amax_publish(unsigned m, unsigned *dst) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, m);
+}
 
 // ------------------------------------------------------------------------ weight packs
 // fwd pack: Bp[n][k] (n < Fo, k < 2Fi) = k < Fi ? W_l[n][k] : W_r[n][k-Fi]
@@ -292,14 +301,24 @@ int launch_gemm(const GemmArgs &a, hipStream_t st) {
 // Epilogue of the wide kernels, straight on the accumulators: acc[i][j][r] is row
 // wm*64 + i*32 + (r&3) + 8(r>>2) + 4(lane>>5), column (wn*TN + j)*32 + (lane&31) of the tile
 // (the C layout is the same for the f32 and the bf16 32x32 MFMAs).
+// cs (nullable): factor per output column applied to the raw accumulators first (the fp16-split
+// kernel computes on operands scaled by powers of two).
 template <int TN, int NWN>   // NWN = column waves of the workgroup (they share the row norms)
 __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][TN], const GemmArgs &a, int64_t row0,
-                                              int n0, int wm, int wn, int lane, float (*rowss)[4]) {
+                                              int n0, int wm, int wn, int lane, float (*rowss)[4],
+                                              const float *__restrict__ cs) {
   constexpr int TM = 2;
   const EpiArgs &e = a.epi;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + (lane & 31);   // global output column
+    if (cs) {
+      const float sc = cs[n];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= sc;
+    }
     if (e.mode != MODE_DX) {
       const float b = e.bias[n];
 #pragma unroll
@@ -348,6 +367,7 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][TN], const GemmAr
         if (wn == 0 && (lane & 31) == 0 && e.rnorm && row0 + lr < a.M) e.rnorm[row0 + lr] = rn;
       }
   }
+  unsigned amx = 0u;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -363,11 +383,13 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][TN], const GemmAr
         if (grow < a.M) {
           float v = acc[i][j][r];
           if (e.mode == MODE_DX && !second && e.row_scale) v *= e.row_scale[grow];
+          amx = max(amx, __float_as_uint(v) & 0x7FFFFFFFu);
           if (a.c_blk && !second) C[(int64_t)(col >> 6) * a.c_blk + grow * 64 + (col & 63)] = v;
           else C[grow * ldc + col] = v;
         }
       }
   }
+  if (e.amax_out) amax_publish(amx, e.amax_out);
 }
 
 // ---- wide layers (128 / 256 columns): 128-row tiles, 8 waves (2 x 4), each wave 64 rows x
@@ -466,7 +488,7 @@ __global__ void __launch_bounds__(512, 4) gemm_wide_k(GemmArgs a) {
 #undef WIDE_GLOAD
 #undef WIDE_SSTORE
 
-  wide_epilogue<TN, 4>(acc, a, row0, n0, wm, wn, lane, rowss);
+  wide_epilogue<TN, 4>(acc, a, row0, n0, wm, wn, lane, rowss, nullptr);
 }
 
 template <int TN>
@@ -522,7 +544,8 @@ __global__ void split_planes_k(const float *__restrict__ bp, int total, uint16_t
 // two halves of the stage double-buffered and the DMA issued a step ahead -- one barrier per 48
 // MFMAs instead of two per 96 -- 17.1 ms against 14.7 ms per 256 -> 256 layer at 10 M rows.)
 template <int TN>   // 32-column blocks per wave: 4 -> 256-column tiles, 2 -> 128-column tiles
-__global__ void __launch_bounds__(256, 2) gemm_split_k(GemmArgs a, const uint16_t *__restrict__ Bpl) {
+__device__ __forceinline__ void split3_tile(const GemmArgs &a, const uint16_t *__restrict__ Bpl,
+                                            const int64_t row0, const int n0) {
   constexpr int BM = 128, BN = 64 * TN, TM = 2;
   constexpr int NA = BM * 8 / 256;                       // float4 of A per thread per chunk
   constexpr int PLANE = (BM + BN) * 32;                  // bf16 per plane (A rows, then B rows)
@@ -530,8 +553,6 @@ __global__ void __launch_bounds__(256, 2) gemm_split_k(GemmArgs a, const uint16_
   float (*rowss)[4] = (float (*)[4])(s256_smem + 3 * PLANE);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1;
-  const int64_t row0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
   const int K = a.K, K1 = a.K1, K2 = a.K - a.K1;
   const int64_t plane_elems = (int64_t)a.Ncols * K;
 
@@ -655,7 +676,482 @@ __global__ void __launch_bounds__(256, 2) gemm_split_k(GemmArgs a, const uint16_
 #undef S256_SPLIT_A
 #undef S256_STORE_A
 #undef S256_GLDS_B
-  wide_epilogue<TN, 2>(acc, a, row0, n0, wm, wn, lane, rowss);
+  wide_epilogue<TN, 2>(acc, a, row0, n0, wm, wn, lane, rowss, nullptr);
+}
+
+template <int TN>
+__global__ void __launch_bounds__(256, 2) gemm_split_k(GemmArgs a, const uint16_t *__restrict__ Bpl) {
+  split3_tile<TN>(a, Bpl, (int64_t)blockIdx.x * 128, blockIdx.y * 64 * TN);
+}
+
+// ---- the wide layers on the fp16 matrix pipe: half the matrix work of the bf16 scheme.
+// With an 11-bit significand TWO parts carry 22 bits (x1 = rn16(x), x2 = rn16(x - x1); the
+// subtraction is exact), and three products (a1 b1, a1 b2, a2 b1) leave a relative error of
+// ~3 * 2^-22 per product: between fp32's own rounding and four times it.  What fp16 lacks is
+// range, so both operands are scaled by exact powers of two first:
+//   * every row n of the weight pack by 2^eb[n], its own maximum going to [2^14, 2^15);
+//   * the activations by ONE factor 2^ea taken from their global maximum (a pass of its own, or
+//     a bound the caller knows: `amax_hint`), undone per output column by cs[n] = 2^-(ea+eb[n]).
+// fp16 subnormals are honoured by the conversion and by the MFMA (tools/probes), so an element's
+// absolute error is at most max(2^-22 |x|, 2^-25) in scaled units: a row of A keeps full accuracy
+// while its largest element is within 2^18 of the global maximum.  Rows below that (and
+// operands outside 2^+-40, or holding Inf/NaN) are not guessed at: the workgroup that meets one
+// puts its tile on a list, and the bf16 kernel above recomputes the listed tiles behind this one
+// (all tiles when the list overflows or the scales are unusable).  Same tiling, LDS layout and
+// two-barrier schedule as gemm_split_k, with two planes instead of three.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int H_REDO_CAP = 4096;
+constexpr int H_MAX_COLS = 512;
+struct HalfCtl {
+  float sa;                 // 2^ea
+  unsigned amax_a;          // max |A| as float bits (NaN patterns compare above Inf)
+  int unsafe;               // scales unusable: every tile goes to the bf16 kernel
+  int redo_count;           // tiles listed; > H_REDO_CAP: list overflowed, all tiles
+  float cs[H_MAX_COLS];     // 2^-(ea + eb[n])
+  int redo[H_REDO_CAP];
+};
+
+__global__ void h_ctl_init_k(HalfCtl *c) {
+  c->amax_a = 0u;
+  c->unsafe = 0;
+  c->redo_count = 0;
+}
+
+__global__ void __launch_bounds__(256) absmax_k(const float *__restrict__ p, int64_t n4,
+                                                unsigned *__restrict__ out) {
+  unsigned m = 0u;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const u32x4v v = *(const u32x4v *)(p + 4 * i);
+    const unsigned a = max(v[0] & 0x7FFFFFFFu, v[1] & 0x7FFFFFFFu);
+    const unsigned b = max(v[2] & 0x7FFFFFFFu, v[3] & 0x7FFFFFFFu);
+    m = max(m, max(a, b));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// exponent that takes a maximum with biased exponent E to [2^14, 2^15); false: out of the range
+// this scheme takes on (0 counts as usable, scale 1: every product with it is 0)
+__device__ __forceinline__ bool h_scale_exp(unsigned bits, int *e) {
+  if (bits == 0u) { *e = 0; return true; }
+  const int E = (int)((bits >> 23) & 0xFFu);
+  *e = 14 - (E - 127);
+  return E >= 127 - 40 && E <= 127 + 40;
+}
+
+// one workgroup per row n of the weight pack: its maximum, its two scaled planes, cs[n]
+__global__ void __launch_bounds__(256) h_prep_k(const float *__restrict__ bp, int K, int total,
+                                                const unsigned *__restrict__ amax_hint,
+                                                HalfCtl *__restrict__ c, uint16_t *__restrict__ planes) {
+  __shared__ unsigned wmax[4];
+  const int n = blockIdx.x, t = threadIdx.x;
+  unsigned m = 0u;
+  for (int k = t; k < K; k += 256) m = max(m, __float_as_uint(bp[(int64_t)n * K + k]) & 0x7FFFFFFFu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((t & 63) == 0) wmax[t >> 6] = m;
+  __syncthreads();
+  m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+  int ea, eb;
+  const bool ok_a = h_scale_exp(amax_hint ? *amax_hint : c->amax_a, &ea);
+  const bool ok_b = h_scale_exp(m, &eb);
+  const float sb = ldexpf(1.f, eb);
+  for (int k = t; k < K; k += 256) {
+    const float v = bp[(int64_t)n * K + k] * sb;
+    const _Float16 h1 = (_Float16)v;
+    const _Float16 h2 = (_Float16)(v - (float)h1);
+    union { _Float16 f; uint16_t u; } u1, u2;
+    u1.f = h1; u2.f = h2;
+    // chunk-major, in the LDS image's own order (32-k rows, 16-byte slots XOR-ed with the row's
+    // swizzle): a DMA piece of the GEMM reads 1 KiB of consecutive bytes
+    const int64_t off = ((int64_t)(k >> 5) * gridDim.x + n) * 32 + ((((k & 31) >> 3) ^ ((n >> 2) & 3)) * 8) + (k & 7);
+    planes[off] = u1.u;
+    planes[(int64_t)total + off] = u2.u;
+  }
+  if (t == 0) {
+    c->cs[n] = ldexpf(1.f, -(ea + eb));
+    if (n == 0) c->sa = ldexpf(1.f, ea);
+    if (!(ok_a && ok_b)) c->unsafe = 1;
+  }
+}
+
+// Epilogue for accumulators computed TRANSPOSED (MFMA operands swapped: weights as A, activations
+// as B): acc[i][j][4q + e] is output row wm*64 + i*32 + (lane & 31), column
+// (wn*TN + j)*32 + 8q + 4(lane >> 5) + e of the tile, i.e. every lane holds runs of four consecutive
+// columns of ONE output row and stores them as 16 bytes: 32 store instructions per thread and
+// tile instead of 128 (a CU retires a store instruction every ~40 cycles whatever its width, and
+// 128 of them per thread cost as much as the tile's matrix work).
+template <int TN, int NWN>
+__device__ __forceinline__ void wide_epilogue_t(f32x16 (&acc)[2][TN], const GemmArgs &a, int64_t row0,
+                                                int n0, int wm, int wn, int lane, float (*rowss)[4],
+                                                const float *__restrict__ cs) {
+  constexpr int TM = 2;
+  const EpiArgs &e = a.epi;
+  const int h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + (wn * TN + j) * 32 + 8 * q + 4 * h;      // first of four output columns
+      const float4 sc = cs ? *(const float4 *)(cs + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 b = e.mode != MODE_DX ? *(const float4 *)(e.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int64_t grow = row0 + wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float v = acc[i][j][4 * q + c] * f4c(sc, c) + f4c(b, c);
+          if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) v = fmaxf(v, 0.f);
+          if (e.mode == GSAGE_EPI_RELU_DROPOUT && grow < a.M) {
+            const uint64_t idx = (uint64_t)grow * (uint64_t)a.Ncols + (uint64_t)(n + c);
+            const bool keep = e.keep_mask ? (e.keep_mask[idx] != 0) : dropout_keep(e.seed, idx, e.p);
+            v = keep ? v * e.inv_keep : 0.f;
+          }
+          acc[i][j][4 * q + c] = v;
+        }
+      }
+    }
+  if (e.mode == GSAGE_EPI_L2NORM) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ss += acc[i][j][r] * acc[i][j][r];
+      ss += __shfl_xor(ss, 32, 64);
+      if (h == 0) rowss[wm * 64 + i * 32 + (lane & 31)][wn] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int lr = wm * 64 + i * 32 + (lane & 31);
+      float ss = rowss[lr][0];
+#pragma unroll
+      for (int q = 1; q < NWN; ++q) ss += rowss[lr][q];
+      const float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= rn;
+      if (wn == 0 && h == 0 && e.rnorm && row0 + lr < a.M) e.rnorm[row0 + lr] = rn;
+    }
+  }
+  unsigned amx = 0u;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t grow = row0 + wm * 64 + i * 32 + (lane & 31);
+    if (grow < a.M) {
+      const float rs = (e.mode == MODE_DX && e.row_scale) ? e.row_scale[grow] : 1.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nj = n0 + (wn * TN + j) * 32;
+        const bool second = nj >= a.N1;                    // uniform over the wave (N1 % 32 == 0)
+        float *C = second ? a.C2 : a.C1;
+        const int ldc = second ? (a.Ncols - a.N1) : a.N1;
+        const float f = second ? 1.f : rs;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = (second ? nj - a.N1 : nj) + 8 * q + 4 * h;
+          const float4 v = make_float4(acc[i][j][4 * q] * f, acc[i][j][4 * q + 1] * f,
+                                       acc[i][j][4 * q + 2] * f, acc[i][j][4 * q + 3] * f);
+          float *dst = (a.c_blk && !second) ? C + (int64_t)(col >> 6) * a.c_blk + grow * 64 + (col & 63)
+                                            : C + grow * ldc + col;
+          *(float4 *)dst = v;
+          amx = max(max(amx, __float_as_uint(v.x) & 0x7FFFFFFFu), __float_as_uint(v.y) & 0x7FFFFFFFu);
+          amx = max(max(amx, __float_as_uint(v.z) & 0x7FFFFFFFu), __float_as_uint(v.w) & 0x7FFFFFFFu);
+        }
+      }
+    }
+  }
+  if (e.amax_out) amax_publish(amx, e.amax_out);
+}
+
+// 512 threads = 8 waves as 4 x 2, each 64 rows x 32 TN columns; ONE persistent workgroup per CU
+// walks 256-row tiles, and the K loops of all its tiles run as ONE sequence of 32-k chunks over
+// two LDS stages, one barrier per chunk:
+//   chunk g computes on stage g&1 while   the LDS-DMA of the weights of chunk g+1,
+//                                         the split + ds_write of the activations of chunk g+1
+//                                         (in registers since chunk g-1) fill stage (g+1)&1,
+//                                   and   the global loads of the activations of chunk g+2 start.
+// The barrier waits for the DMA but leaves those last loads in flight (vmcnt counts in issue
+// order: the DMA is issued first, an empty asm keeps the compiler from moving the loads above
+// it).  Chunks run on across tile boundaries, so a tile's epilogue stores drain underneath the
+// next tile's first chunks.  The loop is ISSUE-bound before it is anything else (two waves per
+// SIMD share one issue port with their 96 MFMAs per chunk), so everything a thread needs per
+// chunk is a constant offset from a handful of values computed once: LDS addresses with
+// immediate offsets, global addresses as a uniform base plus a 32-bit lane offset.
+#ifdef HB_PROF
+__device__ unsigned long long hb_prof[2][256][8];
+#define HB_STAMP(K) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_[K] += now_ - last_; last_ = now_; }
+#else
+#define HB_STAMP(K)
+#endif
+#define HB_WAIT_BARRIER(VM)                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int TN>
+__global__ void __launch_bounds__(512, 1) gemm_half_k(GemmArgs a, const uint16_t *__restrict__ Bpl,
+                                                      HalfCtl *__restrict__ ctl) {
+  constexpr int BM = 256, BN = 64 * TN, TM = 2;
+  constexpr int NA = BM * 8 / 512;                       // float4 of A per thread per chunk
+  constexpr int PLANE = (BM + BN) * 32;                  // fp16 per plane (A rows, then B rows)
+  constexpr int STAGE = 2 * PLANE;
+  extern __shared__ __align__(16) uint16_t hb_smem[];    // 2 stages x 2 planes, then rowss
+  float (*rowss)[4] = (float (*)[4])(hb_smem + 2 * STAGE);
+  if (ctl->unsafe) return;                               // written before this launch: uniform
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int K = a.K, K1 = a.K1;
+  const int ny = a.Ncols / BN, nysh = ny - 1, nk = K >> 5;     // ny is 1 or 2 (launcher)
+  const int ntiles = (int)(((a.M + BM - 1) / BM) * ny);
+  const int64_t plane_elems = (int64_t)a.Ncols * K;
+  const float sa = ctl->sa;
+  if ((int)blockIdx.x >= ntiles) return;
+
+  // The workgroup's chunks are numbered g = 0, 1, ...: chunk g belongs to its tile number
+  // g / nk, i.e. tile blockIdx.x + (g / nk) gridDim.x, and covers k = 32 ((g + rot) % nk): the
+  // workgroups start their K loops at different chunks (and a tile continues where the last one
+  // stopped), so that they do not all ask L2 for the same weight lines at the same moment.
+  // nk is a power of two (launcher).
+  const int lognk = 31 - __builtin_clz(nk);
+  const int rot = (int)((blockIdx.x * 5u) & (unsigned)(nk - 1));
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int nchunks = my_tiles << lognk;
+  struct Pos { int g; };
+  auto tile_of = [&](const Pos &p) { return (int)blockIdx.x + (p.g >> lognk) * (int)gridDim.x; };
+  auto kc_of = [&](const Pos &p) { return ((p.g + rot) & (nk - 1)) << 5; };
+  auto row0_of = [&](const Pos &p) { return (int64_t)(tile_of(p) >> nysh) * BM; };
+  auto n0_of = [&](const Pos &p) { return (tile_of(p) & nysh) * BN; };
+
+  // ---- per-thread constants
+  // staging of A: thread t owns 4 consecutive k (float4 number t & 7 of the 32-k row) of rows
+  // (t >> 3) + 64 i; their LDS slots differ by a constant, their global rows by a stride
+  const int arow = t >> 3, ac4 = t & 7;
+  const uint32_t a_stride = a.a_blk ? 256u : (uint32_t)K1 * 4u;      // bytes between rows of A
+  const uint32_t smem_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t *)hb_smem;
+  const uint32_t a_lds_b =
+      smem_b + 2u * (uint32_t)(arow * 32 + (((ac4 >> 1) ^ ((arow >> 2) & 3)) * 8) + (ac4 & 1) * 4);   // bytes
+  // MFMA fragments: lane = row (lane & 31) of a 32-row block, 8 k at 16-byte slot 2 ks + (lane >> 5)
+  // XOR-ed with the row's swizzle, which is the same for every block: one offset, and ks = 1 is ^ 16
+  const int fsw = ((lane & 31) >> 2) & 3;
+  const int f_off = (lane & 31) * 32 + (((fsw & 2) | ((lane >> 5) ^ (fsw & 1))) * 8);
+  const uint16_t *const fa_lds = hb_smem + wm * 64 * 32;
+  const uint16_t *const fb_lds = hb_smem + (BM + wn * TN * 32) * 32;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4v ra[NA];
+  float rmax[NA];          // largest |a| in this thread's slice of its NA rows of the tile being staged
+  bool bad = false;        // ... found a row of a finished staging that lost bits
+#pragma unroll
+  for (int i = 0; i < NA; ++i) rmax[i] = 0.f;
+
+  // rows past M are read as the tile's last row (their outputs are not stored)
+#define HB_GLOAD_A(P)                                                                         \
+  {                                                                                           \
+    const int64_t r0 = row0_of(P);                                                            \
+    const int kc = kc_of(P);                                                                  \
+    const bool first = kc < K1;                                                               \
+    const int kk = first ? kc : kc - K1;                                                      \
+    const float *b = first ? a.A1 : a.A2;                                                     \
+    const char *base = (const char *)(a.a_blk ? b + (int64_t)(kk >> 6) * a.a_blk + r0 * 64 + (kk & 63) \
+                                              : b + r0 * (int64_t)(first ? K1 : K - K1) + kk); \
+    const int64_t left = a.M - r0;                                                            \
+    const int last = (int)(left < BM ? left : BM) - 1;                                        \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                          \
+      const int row = arow + 64 * i;                                                          \
+      const uint32_t off = (uint32_t)(row < last ? row : last) * a_stride + (uint32_t)ac4 * 16u; \
+      ra[i] = *(const f32x4v *)(base + off);                                                  \
+    }                                                                                         \
+  }
+  // rows of a finished tile are judged when the staging moves on to the next tile
+#define HB_ROWS_DONE()                                                                        \
+  {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                          \
+      float m = rmax[i];                                                                      \
+      m = fmaxf(m, __shfl_xor(m, 1, 64));                                                     \
+      m = fmaxf(m, __shfl_xor(m, 2, 64));                                                     \
+      m = fmaxf(m, __shfl_xor(m, 4, 64));                                                     \
+      /* too small to keep its bits, or (a bound that was too low) beyond what fp16 holds */  \
+      bad |= (m > 0.f && m * sa < 0.125f) || !(m * sa < 65504.f);                             \
+      rmax[i] = 0.f;                                                                          \
+    }                                                                                         \
+  }
+#define HB_SPLIT_STORE_A(ST)                                                                  \
+  {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                          \
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(rmax[i]) : "v"(ra[i][0]), "v"(ra[i][1]));    \
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(rmax[i]) : "v"(ra[i][2]), "v"(ra[i][3]));    \
+      f16x4 p1, p2;                                                                           \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                         \
+        p1[c] = (_Float16)(ra[i][c] * sa);                                                    \
+        p2[c] = (_Float16)__builtin_fmaf(ra[i][c], sa, -(float)p1[c]);                        \
+      }                                                                                       \
+      /* written by asm: behind an LDS-DMA the compiler puts vmcnt(0) in front of every LDS    \
+         store of its own, which would wait for the DMA (and the loads behind it) right here */ \
+      asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a_lds_b + (ST) * (STAGE * 2)),       \
+                   "v"(__builtin_bit_cast(uint64_t, p1)), "n"(i * 64 * 64) : "memory");       \
+      asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a_lds_b + (ST) * (STAGE * 2)),       \
+                   "v"(__builtin_bit_cast(uint64_t, p2)), "n"(PLANE * 2 + i * 64 * 64) : "memory"); \
+    }                                                                                         \
+  }
+  // the planes are stored chunk-major in the LDS image's own order (h_prep_k): a piece is 1 KiB
+  // of consecutive bytes = 16 weight rows of 32 k
+#define HB_GLDS_B(P, ST)                                                                      \
+  {                                                                                           \
+    const uint16_t *src0 = Bpl + ((int64_t)(kc_of(P) >> 5) * a.Ncols + n0_of(P)) * 32 + lane * 8; \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                          \
+      _Pragma("unroll") for (int q = 0; q < TN / 2; ++q) {                                    \
+        const int blk = q * 8 + w;                                                            \
+        const uint16_t *src = src0 + pl * plane_elems + blk * 16 * 32;                        \
+        const uint32_t dst = smem_b + 2u * (uint32_t)((ST) * STAGE + pl * PLANE + (BM + blk * 16) * 32); \
+        /* issued by asm: the compiler answers an LDS-DMA it knows of with vmcnt(0) in front   \
+           of the next LDS store and the next global load, i.e. waits for it on the spot */    \
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src),        \
+                     "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");                    \
+      }                                                                                       \
+  }
+#define HB_MFMA(ST, KS)                                                                       \
+  {                                                                                           \
+    const int fo = (ST) * STAGE + ((KS) ? f_off ^ 16 : f_off);                                \
+    f16x8 af[TM][2];                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
+      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                        \
+        af[i][pl] = *(const f16x8 *)(fa_lds + fo + pl * PLANE + i * 32 * 32);                 \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                          \
+      f16x8 bf[2];                                                                            \
+      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                        \
+        bf[pl] = *(const f16x8 *)(fb_lds + fo + pl * PLANE + j * 32 * 32);                    \
+      /* small terms first, so that they are not rounded away against the big partial sums */ \
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[0][1], acc[0][j], 0, 0, 0); \
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[1][1], acc[1][j], 0, 0, 0); \
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1], af[0][0], acc[0][j], 0, 0, 0); \
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[1], af[1][0], acc[1][j], 0, 0, 0); \
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[0][0], acc[0][j], 0, 0, 0); \
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[0], af[1][0], acc[1][j], 0, 0, 0); \
+    }                                                                                         \
+  }
+
+  // Every workgroup has the same work per tile, and a tile ends in a burst of 256 KiB of
+  // stores: started together, all CUs would write at the same moments (the stores then drain at
+  // the chip's write rate while nothing computes) and read at the same moments.  Sixteen
+  // start phases a sixteenth of a tile apart spread both streams evenly over time.
+  for (int i = (int)(blockIdx.x & 15u) * nk; i > 0; --i) __builtin_amdgcn_s_sleep(5);
+  // prologue: chunk 0 into stage 0, chunk 1's activations into registers
+  {
+    const Pos p0{0}, p1{1};
+    HB_GLDS_B(p0, 0)
+    HB_GLOAD_A(p0)
+    HB_SPLIT_STORE_A(0)
+    if (nk == 1) HB_ROWS_DONE()                   // a one-chunk K: chunk 1 is the next tile already
+    if (1 < nchunks) HB_GLOAD_A(p1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HB_WAIT_BARRIER(0);
+  }
+#ifdef HB_PROF
+  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
+  for (int g = 0; g < nchunks; ++g) {
+    HB_STAMP(0)
+    // stage g & 1 holds chunk g; registers ra hold the activations of chunk g + 1
+    const int st = g & 1;
+    const Pos pc{g}, pd{g + 1}, pl2{g + 2};
+    const bool have_d = g + 1 < nchunks, have_l = g + 2 < nchunks;
+    // The two waves of a SIMD (w and w + 4) take the chunk's two halves in opposite order: one
+    // stages while the other one's MFMAs have the matrix pipe, then they swap.  In the same
+    // order both would stage together with the pipe idle, then queue for it.
+    if (w < 4) {
+      if (have_d) {
+        HB_SPLIT_STORE_A(st ^ 1)
+        if (((g + 2) & (nk - 1)) == 0) HB_ROWS_DONE() // that was the last chunk of its tile
+      }
+      HB_STAMP(1)
+      if (have_l) HB_GLOAD_A(pl2)
+      asm volatile("" ::: "memory");
+      if (have_d) HB_GLDS_B(pd, st ^ 1)           // last in issue order: the compiler's own waits
+                                                  // in this chunk never cover it
+      HB_STAMP(2)
+      HB_MFMA(st, 0)
+      HB_MFMA(st, 1)
+      HB_STAMP(3)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      HB_STAMP(4)
+    } else {
+      if (have_d) HB_GLDS_B(pd, st ^ 1)           // a whole chunk to land
+      HB_STAMP(2)
+      HB_MFMA(st, 0)
+      HB_MFMA(st, 1)
+      HB_STAMP(3)
+      if (have_d) {
+        HB_SPLIT_STORE_A(st ^ 1)                  // the compiler waits for ra here (vmcnt(0): the
+                                                  // DMA, a chunk old, is covered too)
+        if (((g + 2) & (nk - 1)) == 0) HB_ROWS_DONE()
+      }
+      HB_STAMP(1)
+      if (have_l) {
+        HB_GLOAD_A(pl2)                           // needed at the END of the next chunk
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      HB_STAMP(4)
+    }
+    HB_WAIT_BARRIER(0x3f);
+    HB_STAMP(5)
+    if (((g + 1) & (nk - 1)) == 0) {              // the tile is complete
+      // `bad` as of the staging of this tile's last chunk (one chunk ago, or just now for K = 32)
+      if (__syncthreads_or(bad) && t == 0) {
+        // two 128-row tiles of the list kernel's tiling
+        const int64_t tx = tile_of(pc) >> nysh, ty = tile_of(pc) & nysh;
+        const bool two = (2 * tx + 1) * 128 < a.M;
+        const int slot = atomicAdd(&ctl->redo_count, two ? 2 : 1);
+        if (slot < H_REDO_CAP) ctl->redo[slot] = (int)(2 * tx * ny + ty);
+        if (two && slot + 1 < H_REDO_CAP) ctl->redo[slot + 1] = (int)((2 * tx + 1) * ny + ty);
+      }
+      bad = false;
+      wide_epilogue_t<TN, 2>(acc, a, row0_of(pc), n0_of(pc), wm, wn, lane, rowss, ctl->cs);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      HB_STAMP(6)
+    }
+  }
+#ifdef HB_PROF
+  if ((t == 0 || t == 256) && blockIdx.x < 256)
+    for (int k = 0; k < 8; ++k) hb_prof[t >> 8][blockIdx.x][k] = k == 7 ? (unsigned long long)nchunks : prof_[k];
+#endif
+#undef HB_GLOAD_A
+#undef HB_ROWS_DONE
+#undef HB_SPLIT_STORE_A
+#undef HB_GLDS_B
+#undef HB_MFMA
+}
+
+// the tiles the fp16 kernel would not vouch for, recomputed by the bf16 scheme
+template <int TN>
+__global__ void __launch_bounds__(256, 2) gemm_split_list_k(GemmArgs a, const uint16_t *__restrict__ Bpl,
+                                                            const HalfCtl *__restrict__ ctl) {
+  const int ny = a.Ncols / (64 * TN);
+  const int64_t ntiles = ((a.M + 127) / 128) * ny;
+  const bool all = ctl->unsafe || ctl->redo_count > H_REDO_CAP;
+  const int64_t cnt = all ? ntiles : (int64_t)ctl->redo_count;
+  for (int64_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+    const int64_t tile = all ? i : (int64_t)ctl->redo[i];
+    split3_tile<TN>(a, Bpl, (tile / ny) * 128, (int)(tile % ny) * 64 * TN);
+    __syncthreads();            // the next tile's staging overwrites this one's LDS
+  }
 }
 
 template <int TN>
@@ -670,6 +1166,52 @@ int launch_gemm_split(const GemmArgs &a, uint16_t *planes, hipStream_t st) {
   GSAGE_CHECK_LAUNCH();
   dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.Ncols / BN));
   hipLaunchKernelGGL((gemm_split_k<TN>), grid, dim3(256), lds, st, a, (const uint16_t *)planes);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}
+
+// shapes gemm_half_k<TN> takes (TN = 2: 128-column tiles, 4: 256-column tiles)
+static bool half_shape_ok(const GemmArgs &a, int BN) {
+  const int nk = a.K >> 5;
+  return a.Ncols <= H_MAX_COLS && a.K % 32 == 0 && a.K1 % 32 == 0 && (a.Ncols == BN || a.Ncols == 2 * BN) &&
+         (a.K == a.K1 || a.K == 2 * a.K1) && nk > 0 && (nk & (nk - 1)) == 0;
+}
+// fp16 scheme: control block and planes live behind the fp32 pack (see pack_bytes)
+template <int TN>
+int launch_gemm_half(const GemmArgs &a, uint16_t *planes, HalfCtl *ctl, const unsigned *amax_hint,
+                     hipStream_t st) {
+  constexpr int BN = 64 * TN;
+  constexpr size_t lds = 2 * 2 * (size_t)(256 + BN) * 32 * sizeof(uint16_t) + 256 * 4 * sizeof(float);
+  constexpr size_t lds3 = 3 * (size_t)(128 + BN) * 32 * sizeof(uint16_t) + 128 * 4 * sizeof(float);
+  if (!half_shape_ok(a, BN)) return GSAGE_ERR_UNSUPPORTED;
+  static std::atomic<bool> done[64], done3[64];
+  if (int rc = allow_dynamic_lds(gemm_half_k<TN>, lds, done)) return rc;
+  if (int rc = allow_dynamic_lds(gemm_split_list_k<TN>, lds3, done3)) return rc;
+  const int total = a.Ncols * a.K;
+  hipLaunchKernelGGL(h_ctl_init_k, dim3(1), dim3(1), 0, st, ctl);
+  GSAGE_CHECK_LAUNCH();
+  if (!amax_hint) {
+    const int64_t n1 = a.M * a.K1 / 4, n2 = a.M * (a.K - a.K1) / 4;
+    hipLaunchKernelGGL(absmax_k, dim3(gs_grid(n1, 256 * 8, 2048)), dim3(256), 0, st, a.A1, n1,
+                       &ctl->amax_a);
+    if (n2)
+      hipLaunchKernelGGL(absmax_k, dim3(gs_grid(n2, 256 * 8, 2048)), dim3(256), 0, st, a.A2, n2,
+                         &ctl->amax_a);
+    GSAGE_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(h_prep_k, dim3(a.Ncols), dim3(256), 0, st, a.Bp, a.K, total, amax_hint, ctl,
+                     planes);
+  GSAGE_CHECK_LAUNCH();
+  const int64_t ntiles = ((a.M + 255) / 256) * (a.Ncols / BN);
+  hipLaunchKernelGGL((gemm_half_k<TN>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), lds,
+                     st, a, (const uint16_t *)planes, ctl);
+  GSAGE_CHECK_LAUNCH();
+  // the tiles it listed (normally none: the kernel below then finds an empty list and leaves)
+  hipLaunchKernelGGL(split_planes_k, dim3(gs_grid(total, 256, 256)), dim3(256), 0, st, a.Bp, total,
+                     planes);
+  GSAGE_CHECK_LAUNCH();
+  hipLaunchKernelGGL((gemm_split_list_k<TN>), dim3(512), dim3(256), lds3, st, a,
+                     (const uint16_t *)planes, (const HalfCtl *)ctl);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }
@@ -1126,6 +1668,7 @@ project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
   const float *src = q < 2 ? agg + 4 * q : x + 4 * (q - 2);
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
+  unsigned amx = 0u;
   for (int64_t r0 = wave0 * 16; r0 < N; r0 += nwaves * 16) {
     const int64_t row = r0 + rl;
     const bool live = row < N;
@@ -1189,6 +1732,8 @@ project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
         float *dst = out_blk ? out + (int64_t)blockIdx.y * out_blk + orow * 64 + rl * 4
                              : out + orow * Fo + cb + rl * 4;
         *(float4 *)dst = o;
+        amx = max(max(amx, __float_as_uint(o.x) & 0x7FFFFFFFu), __float_as_uint(o.y) & 0x7FFFFFFFu);
+        amx = max(max(amx, __float_as_uint(o.z) & 0x7FFFFFFFu), __float_as_uint(o.w) & 0x7FFFFFFFu);
       }
       if (sign) {
         // which outputs are positive, for the backward's ReLU'/dropout' (gsage_relu_sign_words):
@@ -1203,6 +1748,7 @@ project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
       }
     }
   }
+  if (e.amax_out) amax_publish(amx, e.amax_out);
 }
 
 // the word behind the sign bits says whether the forward kernel that ran filled them in
@@ -1545,8 +2091,11 @@ int num_slabs(int64_t N) {
 static size_t pack_f32_bytes(int64_t Fi, int64_t Fo) {
   return gs_align_up((size_t)(2 * Fi * Fo) * sizeof(float), 256);
 }
-static size_t pack_bytes(int64_t Fi, int64_t Fo) {
-  return pack_f32_bytes(Fi, Fo) + gs_align_up((size_t)(3 * 2 * Fi * Fo) * sizeof(uint16_t), 256);
+static size_t pack_planes_bytes(int64_t Fi, int64_t Fo) {
+  return gs_align_up((size_t)(3 * 2 * Fi * Fo) * sizeof(uint16_t), 256);
+}
+static size_t pack_bytes(int64_t Fi, int64_t Fo) {   // fp32 pack | bf16/fp16 planes | HalfCtl
+  return pack_f32_bytes(Fi, Fo) + pack_planes_bytes(Fi, Fo) + gs_align_up(sizeof(HalfCtl), 256);
 }
 // GSAGE_WIDE_GEMM=f32 keeps the wide layers on the fp32 MFMA kernels, =split puts every 256-column
 // tile on the bf16-split kernel whatever its K (A/B measurements, tests); unset: chosen by shape
@@ -1554,17 +2103,28 @@ static int wide_gemm_mode() {
   static const int v = [] {
     const char *e = getenv("GSAGE_WIDE_GEMM");
     if (!e) return -1;
-    return e[0] == 'f' ? 0 : e[0] == 's' ? 1 : -1;
+    return e[0] == 'f' ? 0 : e[0] == 's' ? 1 : e[0] == 'h' ? 2 : -1;
   }();
   return v;
 }
 static int launch_wide(int ncols, const GemmArgs &a, void *pack_base, int64_t Fi, int64_t Fo,
-                       hipStream_t st) {
+                       const unsigned *amax_in, hipStream_t st) {
   uint16_t *planes = (uint16_t *)((char *)pack_base + pack_f32_bytes(Fi, Fo));
   // the split kernels win where the K loop is long (256 -> 256 at 10 M rows: 14.7 vs 22.8 ms;
   // 128 -> 128: 5.3 vs 6.7 ms) and tie on the shortest one in use (the dX GEMM of a 128-wide
   // layer, K = 128), so every wide GEMM takes them unless GSAGE_WIDE_GEMM=f32 says otherwise
   const int mode = wide_gemm_mode();
+  // fp16 kernel (two planes, three products): forwards onto 256 columns with K >= 256, where it
+  // beats the bf16 scheme also when it has to find max |A| itself (256 -> 256 at 2.56 M rows:
+  // 3.6 ms with its two absmax passes, 2.8 ms with a bound handed in, against 4.6 ms); on
+  // 128-column tiles the two tie.  Not for the dX GEMM: rows of a gradient differ by many orders
+  // of magnitude, most tiles would be recomputed.
+  if ((mode == 2 || (mode == -1 && ncols == 256 && a.K >= 256 && a.epi.mode != MODE_DX)) &&
+      half_shape_ok(a, ncols == 128 ? 128 : 256)) {
+    HalfCtl *ctl = (HalfCtl *)((char *)planes + pack_planes_bytes(Fi, Fo));
+    return ncols == 128 ? launch_gemm_half<2>(a, planes, ctl, amax_in, st)
+                        : launch_gemm_half<4>(a, planes, ctl, amax_in, st);
+  }
   if (mode != 0 && (mode == 1 || a.K >= 128))
     return ncols == 128 ? launch_gemm_split<2>(a, planes, st) : launch_gemm_split<4>(a, planes, st);
   return ncols == 128 ? launch_gemm_wide<1>(a, st) : launch_gemm_wide<2>(a, st);
@@ -1580,12 +2140,22 @@ extern "C" size_t gsage_relu_sign_bytes(int64_t N, int64_t Fo) {
   return (size_t)(((N + 3) / 4) * 4 * ((Fo + 63) / 64) + 1) * sizeof(uint64_t);
 }
 
+__global__ void zero_word_k(uint32_t *w) { *w = 0u; }
+
+// forward shapes whose kernel publishes max |out| (EpiArgs::amax_out): the first-layer MFMA kernel
+// and the wide tile kernels
+extern "C" int gsage_project_fwd_range_supported(int64_t Fi, int64_t Fo, int epilogue) {
+  const bool first = Fi == 8 && Fo % 64 == 0 && (Fo == 64 || epilogue != GSAGE_EPI_L2NORM);
+  const bool wide = mfma_dim(Fi) && (Fo == 128 || Fo == 256);
+  return first || wide ? 1 : 0;
+}
+
 static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
                             const float *b_l, const float *w_r, int64_t N, int64_t Fi,
                             int64_t Fo, int epilogue, const uint8_t *keep_mask,
                             uint64_t seed, float p, float *out, float *rnorm, void *wpack,
                             int force_generic, uint64_t *relu_sign, int64_t in_blk, int64_t out_blk,
-                            gsage_stream_t stream) {
+                            const uint32_t *amax_in, uint32_t *amax_out, gsage_stream_t stream) {
   if (N < 0 || Fi <= 0 || Fo <= 0 || !agg || !x || !w_l || !b_l || !w_r || !out || !wpack)
     return GSAGE_ERR_INVALID_ARG;
   if (epilogue < GSAGE_EPI_NONE || epilogue > GSAGE_EPI_L2NORM) return GSAGE_ERR_INVALID_ARG;
@@ -1599,8 +2169,15 @@ static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
                       (!in_blk || Fi >= 128);
     if (force_generic != 0 || !(first || wide)) return GSAGE_ERR_UNSUPPORTED;
   }
-  if (N == 0) return GSAGE_OK;
+  if (amax_out && amax_in == amax_out) return GSAGE_ERR_INVALID_ARG;
   hipStream_t st = gs_stream(stream);
+  if (amax_out) {
+    // only the kernels behind gsage_project_fwd_range_supported publish it
+    if (force_generic != 0 || !gsage_project_fwd_range_supported(Fi, Fo, epilogue)) return GSAGE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(zero_word_k, dim3(1), dim3(1), 0, st, amax_out);
+    GSAGE_CHECK_LAUNCH();
+  }
+  if (N == 0) return GSAGE_OK;
   // only the first-layer MFMA kernel leaves sign bits; the word behind them tells the backward
   bool sign_written = false;
   uint64_t *sign_flag = relu_sign ? relu_sign + ((N + 3) / 4) * 4 * ((Fo + 63) / 64) : nullptr;
@@ -1617,6 +2194,7 @@ static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
   e.inv_keep = epilogue == GSAGE_EPI_RELU_DROPOUT ? 1.0f / (1.0f - p) : 1.0f;
   e.rnorm = rnorm;
   e.row_scale = nullptr;
+  e.amax_out = amax_out;
   float *wp = (float *)wpack;
   const int fi = (int)Fi, fo = (int)Fo;
   const int pack_grid = gs_grid(2 * Fi * Fo, 256, 64);
@@ -1636,7 +2214,7 @@ static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
     a.A1 = agg; a.A2 = x; a.Bp = wp; a.C1 = out; a.C2 = nullptr;
     a.M = N; a.K1 = fi; a.K = 2 * fi; a.N1 = fo; a.Ncols = fo; a.epi = e;
     a.a_blk = in_blk; a.c_blk = out_blk;
-    if (force_generic == 0 && (fo == 128 || fo == 256)) return launch_wide(fo, a, wpack, Fi, Fo, st);
+    if (force_generic == 0 && (fo == 128 || fo == 256)) return launch_wide(fo, a, wpack, Fi, Fo, amax_in, st);
     return launch_gemm_bn(fo, a, st);
   }
   hipLaunchKernelGGL(pack_t_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
@@ -1669,7 +2247,7 @@ extern "C" int gsage_project_fwd_ex(const float *agg, const float *x, const floa
                                     int force_generic, uint64_t *relu_sign,
                                     gsage_stream_t stream) {
   return project_fwd_impl(agg, x, w_l, b_l, w_r, N, Fi, Fo, epilogue, keep_mask, seed, p, out, rnorm,
-                          wpack, force_generic, relu_sign, 0, 0, stream);
+                          wpack, force_generic, relu_sign, 0, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int gsage_project_fwd_blocked_supported(int64_t Fi, int64_t Fo, int in_blocked,
@@ -1682,11 +2260,12 @@ extern "C" int gsage_project_fwd_blocked_supported(int64_t Fi, int64_t Fo, int i
   return first || wide ? 1 : 0;
 }
 
-extern "C" int gsage_project_fwd_blocked(const float *agg, const float *x, const float *w_l,
-                                         const float *b_l, const float *w_r, int64_t N, int64_t Fi,
-                                         int64_t Fo, int epilogue, float *out, float *rnorm,
-                                         void *wpack, int in_blocked, int out_blocked,
-                                         gsage_stream_t stream) {
+extern "C" int gsage_project_fwd_range(const float *agg, const float *x, const float *w_l,
+                                       const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                                       int64_t Fo, int epilogue, float *out, float *rnorm,
+                                       void *wpack, int in_blocked, int out_blocked,
+                                       const uint32_t *amax_in, uint32_t *amax_out,
+                                       gsage_stream_t stream) {
   if (epilogue == GSAGE_EPI_RELU_DROPOUT) return GSAGE_ERR_UNSUPPORTED;   // inference layouts
   if (!gsage_project_fwd_blocked_supported(Fi, Fo, in_blocked, out_blocked, epilogue))
     return GSAGE_ERR_UNSUPPORTED;
@@ -1694,7 +2273,16 @@ extern "C" int gsage_project_fwd_blocked(const float *agg, const float *x, const
     return GSAGE_ERR_UNSUPPORTED;       // the tile kernels need 16-byte aligned operands
   return project_fwd_impl(agg, x, w_l, b_l, w_r, N, Fi, Fo, epilogue, nullptr, 0, 0.f, out, rnorm,
                           wpack, 0, nullptr, in_blocked ? N * 64 : 0, out_blocked ? N * 64 : 0,
-                          stream);
+                          amax_in, amax_out, stream);
+}
+
+extern "C" int gsage_project_fwd_blocked(const float *agg, const float *x, const float *w_l,
+                                         const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                                         int64_t Fo, int epilogue, float *out, float *rnorm,
+                                         void *wpack, int in_blocked, int out_blocked,
+                                         gsage_stream_t stream) {
+  return gsage_project_fwd_range(agg, x, w_l, b_l, w_r, N, Fi, Fo, epilogue, out, rnorm, wpack,
+                                 in_blocked, out_blocked, nullptr, nullptr, stream);
 }
 
 extern "C" int gsage_project_fwd(const float *agg, const float *x, const float *w_l,
@@ -1821,7 +2409,7 @@ static int project_bwd_impl(const float *grad_out, const float *out, const float
       a.epi.mode = MODE_DX;
       a.epi.row_scale = agg_scale;
       int rc = force_generic != 0 ? launch_gemm_bn(fi, a, st)
-                                  : launch_wide(2 * fi, a, ws, Fi, Fo, st);
+                                  : launch_wide(2 * fi, a, ws, Fi, Fo, nullptr, st);
       if (rc) return rc;
     } else {
       hipLaunchKernelGGL(dx_generic_k, dim3(gs_grid(N, 4, 256 * 16)), dim3(256), 0, st, dp, w_l,
@@ -1906,3 +2494,9 @@ extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const 
                               p, dpre, grad_agg, grad_x, grad_w_l, grad_b, grad_w_r, ws, ws_bytes,
                               force_generic, nullptr, nullptr, stream);
 }
+
+#ifdef HB_PROF
+extern "C" int gsage_debug_hb_prof(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(hb_prof), sizeof(unsigned long long) * 2 * 256 * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -178,18 +178,24 @@ class GraphSAGE(nn.Module):
         pad = 8 - first.in_channels
         w_l, w_r = F.pad(first.lin_l.weight, (0, pad)), F.pad(first.lin_r.weight, (0, pad))
         agg = ops.aggregate_mean(graph, x8)
-        h, _ = ops.project_fwd_blocked(agg, x8, w_l, first.lin_l.bias, w_r, _lib.EPI_RELU, False, True)
+        # every hidden layer leaves max |h| behind (one word, float bits): the bound the next
+        # layer's fp16-split GEMM scales its operands by (the mean of rows of h cannot exceed it),
+        # so that GEMM need not make two passes over its 20 GB of input to find it
+        amax = torch.empty(len(self.convs) - 1, dtype=torch.int32, device=x.device)
+        h, _ = ops.project_fwd_blocked(agg, x8, w_l, first.lin_l.bias, w_r, _lib.EPI_RELU, False, True,
+                                       amax_out=amax[0:1])
         del agg
-        for conv in self.convs[1:-1]:
+        for i, conv in enumerate(self.convs[1:-1]):
             agg = ops.aggregate_mean_blocked(graph, h)
             h, _ = ops.project_fwd_blocked(agg, h, conv.lin_l.weight, conv.lin_l.bias,
-                                           conv.lin_r.weight, _lib.EPI_RELU, True, True)
+                                           conv.lin_r.weight, _lib.EPI_RELU, True, True,
+                                           amax_in=amax[i:i + 1], amax_out=amax[i + 1:i + 2])
             del agg
         last = self.convs[-1]
         epi = _lib.EPI_L2NORM if self.normalize_output else _lib.EPI_NONE
         agg = ops.aggregate_mean_blocked(graph, h)
         out, _ = ops.project_fwd_blocked(agg, h, last.lin_l.weight, last.lin_l.bias,
-                                         last.lin_r.weight, epi, True, False)
+                                         last.lin_r.weight, epi, True, False, amax_in=amax[-1:])
         return out
 
     def get_embedding_dim(self) -> int:

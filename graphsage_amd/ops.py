@@ -149,9 +149,16 @@ def aggregate_mean_blocked(graph: GraphCSR, xb: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def project_fwd_blocked(agg, x, w_l, b_l, w_r, epilogue, in_blocked: bool, out_blocked: bool):
-    """K3 forward with column-blocked operands (gsage_project_fwd_blocked) -> (out, rnorm)."""
+def project_fwd_blocked(agg, x, w_l, b_l, w_r, epilogue, in_blocked: bool, out_blocked: bool,
+                        amax_in: Optional[torch.Tensor] = None,
+                        amax_out: Optional[torch.Tensor] = None):
+    """K3 forward with column-blocked operands (gsage_project_fwd_range) -> (out, rnorm).
+    ``amax_in`` / ``amax_out``: one-word int32 tensors carrying max |activation| as float bits
+    from a layer to the next (the fp16-split GEMM scales its operands by it)."""
     lib = _lib.load()
+    for t in (amax_in, amax_out):
+        if t is not None and (t.dtype != torch.int32 or t.numel() != 1 or not t.is_cuda):
+            raise ValueError("amax_in / amax_out must be one-element int32 tensors on the GPU")
     Fo, Fi = w_l.shape
     N = x.size(1) if in_blocked else x.size(0)
     dev = x.device
@@ -162,13 +169,14 @@ def project_fwd_blocked(agg, x, w_l, b_l, w_r, epilogue, in_blocked: bool, out_b
         ev = _timer.bracket(f"project_fwd_{Fi}x{Fo}") if _timer is not None and _timer.enabled else None
         if ev:
             ev[0].record()
-        rc = lib.gsage_project_fwd_blocked(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(),
-                                           b_l.data_ptr(), w_r.data_ptr(), N, Fi, Fo, int(epilogue),
-                                           out.data_ptr(), _lib.ptr(rnorm), wpack.data_ptr(),
-                                           int(in_blocked), int(out_blocked), _lib.stream_handle())
+        rc = lib.gsage_project_fwd_range(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(),
+                                         b_l.data_ptr(), w_r.data_ptr(), N, Fi, Fo, int(epilogue),
+                                         out.data_ptr(), _lib.ptr(rnorm), wpack.data_ptr(),
+                                         int(in_blocked), int(out_blocked), _lib.ptr(amax_in),
+                                         _lib.ptr(amax_out), _lib.stream_handle())
         if ev:
             ev[1].record()
-    _lib.check(rc, "gsage_project_fwd_blocked")
+    _lib.check(rc, "gsage_project_fwd_range")
     return out, rnorm
 
 

@@ -220,13 +220,37 @@ int gsage_project_bwd_rows(const float *grad_out, const float *out, const float 
  * in_blocked / out_blocked say which side is blocked (agg and x share the input layout); same
  * arithmetic as gsage_project_fwd (the GEMM gives the same bits for the same inputs).  Eval epilogues only
  * (NONE, RELU, L2NORM); gsage_project_fwd_blocked_supported says which shapes have a kernel
- * (8 -> 64k row-major in / blocked out; 128|256 -> 128|256 on the bf16-split GEMM). */
+ * (8 -> 64k row-major in / blocked out; 128|256 -> 128|256 on the split-operand GEMMs). */
 int gsage_project_fwd_blocked_supported(int64_t Fi, int64_t Fo, int in_blocked, int out_blocked,
                                         int epilogue);
 int gsage_project_fwd_blocked(const float *agg, const float *x, const float *w_l,
                               const float *b_l, const float *w_r, int64_t N, int64_t Fi,
                               int64_t Fo, int epilogue, float *out, float *rnorm, void *wpack,
                               int in_blocked, int out_blocked, gsage_stream_t stream);
+
+/* gsage_project_fwd_blocked with the RANGE of the activations handed from layer to layer (a chain
+ * of wide layers in inference, encoder.py:181-185 with hidden_dim 256).  The 256-column forward GEMM
+ * with K >= 256 runs on the fp16 matrix pipe: every fp32 operand as the sum of TWO fp16 numbers
+ * (22 bits), three products per fp32 product, fp32 accumulation -- half the matrix work of the
+ * bf16 scheme at the same accuracy (max error 5e-7 of the largest output; fp32 MFMA: 8e-7),
+ * PROVIDED the operands are scaled into fp16's range first: weights per output column, the
+ * activations by one power of two taken from max |agg|, |x|.  Tiles holding a row whose largest
+ * element is more than 2^18 below that maximum (or above it: a bound that was too low) are
+ * recomputed by the bf16 kernel; Inf/NaN or a maximum outside 2^+-40 sends every tile there.
+ *   amax_in  : uint32 [1] or NULL: an upper bound of |agg| and |x| as IEEE-754 float bits (the
+ *              mean aggregation of x is bounded by max |x|, so the producer's amax_out serves).
+ *              NULL: the library finds the maximum itself (two streaming passes over agg and x,
+ *              +30 % on the GEMM's time).  Ignored by kernels that do not scale.
+ *   amax_out : uint32 [1] or NULL: receives max |out| as float bits (NaN patterns compare above
+ *              Inf).  Must not be amax_in.  Only where gsage_project_fwd_range_supported(Fi, Fo,
+ *              epilogue): the first-layer MFMA kernel (Fi = 8) and the 128/256-column tile kernels;
+ *              GSAGE_ERR_UNSUPPORTED otherwise.
+ * in_blocked = out_blocked = 0 is the plain row-major layout.  Eval epilogues only. */
+int gsage_project_fwd_range_supported(int64_t Fi, int64_t Fo, int epilogue);
+int gsage_project_fwd_range(const float *agg, const float *x, const float *w_l, const float *b_l,
+                            const float *w_r, int64_t N, int64_t Fi, int64_t Fo, int epilogue,
+                            float *out, float *rnorm, void *wpack, int in_blocked, int out_blocked,
+                            const uint32_t *amax_in, uint32_t *amax_out, gsage_stream_t stream);
 
 /* ---------------------------------------------------------- K4 / K5: skip-gram loss
  * K4 replaces SkipGramLoss.forward / forward_with_details (src/model/loss.py:97-136,

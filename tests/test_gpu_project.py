@@ -165,16 +165,18 @@ def test_backward_zero_row_mask(epi, n):
 
 
 def test_wide_shapes_on_both_kernel_families():
-    """The 128/256-wide layers have two kernel families (fp32 MFMA, and bf16 MFMA on the three-way
-    split of every fp32 operand) chosen by shape; GSAGE_WIDE_GEMM forces one.  The library reads
-    it once, so each family runs this file's forward/backward cases in a child process."""
+    """The 128/256-wide layers have three kernel families (fp32 MFMA, bf16 MFMA on the three-way
+    split of every fp32 operand, fp16 MFMA on the range-scaled two-way split) chosen by shape;
+    GSAGE_WIDE_GEMM forces one -- "half" also onto the 128-column tiles and the dX GEMMs it is not
+    chosen for.  The library reads it once, so each family runs this file's forward/backward
+    cases in a child process."""
     import os
     import subprocess
     import sys
     if os.environ.get("GSAGE_WIDE_GEMM"):
         pytest.skip("already inside the forced run")
     here = os.path.dirname(os.path.abspath(__file__))
-    for mode in ("split", "f32"):
+    for mode in ("split", "f32", "half"):
         env = dict(os.environ, GSAGE_WIDE_GEMM=mode)
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
                             os.path.join(here, "test_gpu_project.py"), "-k",
