@@ -564,8 +564,10 @@ def run_inference(args, R):
                   "pack/split, microseconds)",
         "floors_ms": {"mfma": mfma_floor * 1e3, "hbm": hbm_floor * 1e3},
         "other_bound": hbm if bound == "mfma" else mfma,
-        "traffic": None, "launches_timed": launches, "mean_ms": mean_ms if launches else None,
+        "launches_timed": launches, "mean_ms": mean_ms if launches else None,
         "csrc_hash": csrc_hash()})
+    traffic, traffic_src, stale = measured_traffic("c5", kname) if not args.nodes else (None, None, None)
+    roofline.update({"traffic": traffic, "traffic_source": traffic_src, "traffic_stale": stale})
     dtype = {"f32": "f32",
              "bf16x3": "f32 (wide GEMMs: bf16 MFMA on 3-way split fp32 operands, fp32 accumulate)",
              "fp16x2": "f32 (wide GEMMs: fp16 MFMA on 2-way split, range-scaled fp32 operands, fp32 "
