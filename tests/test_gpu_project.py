@@ -103,7 +103,8 @@ def test_inkernel_dropout_matches_host_mirror():
     from graphsage_amd.ops import project_fwd
     from graphsage_amd.rng import dropout_keep_mask
     p, seed = 0.3, 0x1234_5678_9ABC_DEF1
-    for (n, fi, fo, fg) in [(500, 7, 64, False), (200, 64, 64, False), (200, 64, 128, False), (100, 20, 48, False)]:
+    for (n, fi, fo, fg) in [(500, 7, 64, False), (200, 64, 64, False), (200, 64, 128, False), (100, 20, 48, False),
+                           (300, 256, 256, False), (130, 128, 128, False)]:
         agg, x, wl, bl, wr, _, _ = _case(n, fi, fo, 5)
         d = [t.cuda() for t in (agg, x, wl, bl, wr)]
         out, _ = project_fwd(*d, epilogue=_lib.EPI_RELU_DROPOUT, seed=seed, p=p, force_generic=fg)
