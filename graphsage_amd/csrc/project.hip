@@ -697,8 +697,9 @@ __global__ void __launch_bounds__(256, 2) gemm_split_k(GemmArgs a, const uint16_
 // while its largest element is within 2^18 of the global maximum.  Rows below that (and
 // operands outside 2^+-40, or holding Inf/NaN) are not guessed at: the workgroup that meets one
 // puts its tile on a list, and the bf16 kernel above recomputes the listed tiles behind this one
-// (all tiles when the list overflows or the scales are unusable).  Same tiling, LDS layout and
-// two-barrier schedule as gemm_split_k, with two planes instead of three.
+// (all tiles when the list overflows or the scales are unusable; a row ABOVE fp16's range after
+// scaling -- a bound that was too low -- is listed the same way).  Same swizzled 64-byte LDS rows
+// as gemm_split_k, two planes instead of three; the schedule is its own (gemm_half_k below).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int H_REDO_CAP = 4096;
