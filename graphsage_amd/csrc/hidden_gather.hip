@@ -1,0 +1,407 @@
+// K2h: mean aggregation of the FIRST hidden layer, recomputed from that layer's inputs.
+//
+// SAGEConv layer 2 aggregates h1[j] = act(W_l1 . agg1[j] + b1 + W_r1 . x[j]) over the neighbours j
+// of every node (graphsage.py:133-135 feeding :133/:138 of the next layer).  A row of h1 is 64..256
+// floats, but it is a function of 14 numbers: the 7 input features of j and their neighbour mean.
+// The plain gather (aggregate.hip) fetches 256 B..1 KB per neighbour and runs at the fabric's
+// 128-byte-line rate; this kernel fetches the 64-byte row u[j] = [agg1[j] | x[j]] instead (one
+// line per neighbour, and a table a quarter to a sixteenth of the size) and redoes the 16 -> Fo
+// projection on the matrix cores:
+//
+//   out[i,:] = inv_deg[i] * sum_{p in row i} act( [W_l1 | b1 | W_r1 | 0] . [agg1[j] | 1 | x[j] | 0] ),  j = col[p]
+//
+// One wave per destination row and 32-neighbour group: the 32 rows u[j] are the A operand of
+// v_mfma_f32_32x32x16_bf16 (K = 16 is exactly the layer's input width, the bias rides in the
+// padding column 7), every fp32 operand as the exact sum of three bf16 parts and the six largest
+// of the nine products issued, smallest first (project.hip, gemm_split_k: fp32-equivalent
+// accuracy).  The accumulator comes out as D[neighbour][column] with the neighbours in the
+// registers of a lane, so the activation and the sum over the neighbours are in-lane work
+// and only the two lane halves are combined once per destination row.
+//   eval  (RELU):         act = max(., 0)
+//   train (RELU_DROPOUT): act = keep-and-positive bit of (j, column) ? . / (1 - p) : 0, the bits
+//                         being those of the h1 that was stored (its ReLU'/dropout' bits, or
+//                         h1 > 0), so the recomputed rows have the stored rows' zero pattern.
+// The recomputed pre-activation differs from the stored one by fp32 rounding (1e-7 relative).
+#include "gsage_common.h"
+#include "gsage_sort.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int H1_ROWS = 32;       // destination rows per wave (one trip per wave, in-order dispatch)
+#ifndef H1_DEPTH
+#define H1_DEPTH 1
+#endif
+
+// ---- weight planes: Wc[n][k] = k < 7 ? W_l[n][k] : k == 7 ? b[n] : k < 15 ? W_r[n][k-8] : 0,
+// split into three bf16 planes [3][Fo][16]
+__global__ void __launch_bounds__(256) h1_pack_w_k(const float *__restrict__ wl, const float *__restrict__ bl,
+                                                   const float *__restrict__ wr, int Fo,
+                                                   uint16_t *__restrict__ planes) {
+  const int total = Fo * 16;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int n = e >> 4, k = e & 15;
+    const float v = k < 7 ? wl[n * 8 + k] : k == 7 ? bl[n] : k < 15 ? wr[n * 8 + (k - 8)] : 0.f;
+    const uint32_t u1 = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(u1);
+    const uint32_t u2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(u2);
+    planes[e] = (uint16_t)(u1 >> 16);
+    planes[total + e] = (uint16_t)(u2 >> 16);
+    planes[2 * total + e] = (uint16_t)(__float_as_uint(r2) >> 16);
+  }
+}
+
+// ---- the 64-byte rows: u[j] = [agg1[j][0..6], m_lo, x[j][0..6], m_hi].  m = the 64 keep-and-positive
+// bits of row j (Fo = 64, training), bit 16 cc + q of the 64-bit mask = column 4 q + cc: the order
+// the first-layer kernel's ballots come in (gsage_relu_sign_bytes: per 4 rows and column block four
+// 64-bit words, word cc bit l = column 4 (l & 15) + cc of row l >> 4), so a row's mask is the four
+// 16-bit fields of its group's words.  No sign bits (other forward kernels): taken from h1 > 0.
+__global__ void __launch_bounds__(256) h1_pack_u_k(const float *__restrict__ agg1, const float *__restrict__ x8,
+                                                   int64_t N, int train, const float *__restrict__ h1,
+                                                   const unsigned long long *__restrict__ sign,
+                                                   float *__restrict__ U) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // the flag word behind the bits says whether the forward kernel that ran wrote them
+  const bool have_bits = train && sign && sign[((N + 3) >> 2) * 4] != 0ull;
+  if (j >= N) return;
+  f32x4v a0 = *(const f32x4v *)(agg1 + j * 8), a1 = *(const f32x4v *)(agg1 + j * 8 + 4);
+  f32x4v b0 = *(const f32x4v *)(x8 + j * 8), b1 = *(const f32x4v *)(x8 + j * 8 + 4);
+  uint32_t lo = 0u, hi = 0u;
+  if (train) {
+    if (have_bits) {
+      const unsigned long long *w = sign + (j >> 2) * 4;
+      const int sh = 16 * (int)(j & 3);
+      lo = (uint32_t)((w[0] >> sh) & 0xFFFFull) | ((uint32_t)((w[1] >> sh) & 0xFFFFull) << 16);
+      hi = (uint32_t)((w[2] >> sh) & 0xFFFFull) | ((uint32_t)((w[3] >> sh) & 0xFFFFull) << 16);
+    } else {
+      const float *r = h1 + j * 64;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const f32x4v v = *(const f32x4v *)(r + 4 * q);
+        lo |= (v[0] > 0.f ? 1u : 0u) << q | (v[1] > 0.f ? 1u : 0u) << (16 + q);
+        hi |= (v[2] > 0.f ? 1u : 0u) << q | (v[3] > 0.f ? 1u : 0u) << (16 + q);
+      }
+    }
+  }
+  a1[3] = __uint_as_float(lo);
+  b1[3] = __uint_as_float(hi);
+  float *u = U + j * 16;
+  *(f32x4v *)(u) = a0;
+  *(f32x4v *)(u + 4) = a1;
+  *(f32x4v *)(u + 8) = b0;
+  *(f32x4v *)(u + 12) = b1;
+}
+
+// ---- group index: the 32-neighbour groups of every row, cut once per graph.  Row chunk k (rows
+// 32 k .. 32 k + 31, one wave) owns descriptors goff[k] .. goff[k+1]; a descriptor is
+// (p0 = first position in col, meta = row in chunk | count << 8 | last group of its row << 16 |
+// 1 << 17).  A row without neighbours has one descriptor with count 0 (it stores its zero row).
+// With the walk precomputed the wave spends no vector instructions on finding its next group.
+constexpr int H1_META_VALID = 1 << 17, H1_META_LAST = 1 << 16;
+
+__global__ void __launch_bounds__(256) h1_groups_count_k(const int *__restrict__ rowptr, int64_t N,
+                                                         int64_t nchunks, int *__restrict__ counts) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k > nchunks) return;
+  int cnt = 0;
+  if (k < nchunks) {
+    const int64_t r0 = k * H1_ROWS, r1 = r0 + H1_ROWS < N ? r0 + H1_ROWS : N;
+    int prev = rowptr[r0];
+    for (int64_t r = r0; r < r1; ++r) {
+      const int nxt = rowptr[r + 1], deg = nxt - prev;
+      cnt += deg > 0 ? (deg + 31) >> 5 : 1;
+      prev = nxt;
+    }
+  }
+  counts[k] = cnt;                        // counts[nchunks] = 0: the scan leaves the total there
+}
+
+__global__ void __launch_bounds__(256) h1_groups_fill_k(const int *__restrict__ rowptr, int64_t N,
+                                                        int64_t nchunks, const int *__restrict__ goff,
+                                                        int2 *__restrict__ gdesc) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nchunks) return;
+  const int64_t r0 = k * H1_ROWS, r1 = r0 + H1_ROWS < N ? r0 + H1_ROWS : N;
+  int2 *d = gdesc + goff[k];
+  int prev = rowptr[r0];
+  for (int64_t r = r0; r < r1; ++r) {
+    const int nxt = rowptr[r + 1], deg = nxt - prev, rr = (int)(r - r0);
+    if (deg == 0) *d++ = make_int2(prev, rr | H1_META_LAST | H1_META_VALID);
+    for (int off = 0; off < deg; off += 32) {
+      const int left = deg - off;
+      *d++ = make_int2(prev + off, rr | ((left < 32 ? left : 32) << 8) | (left <= 32 ? H1_META_LAST : 0) |
+                                       H1_META_VALID);
+    }
+    prev = nxt;
+  }
+}
+
+struct H1Groups {        // carved from the caller's buffer (gsage_hidden1_groups_bytes)
+  int *goff;             // nchunks + 1 (+ scan block sums behind it)
+  int *bsum;
+  int2 *gdesc;           // at most N + E / 32 descriptors
+};
+static inline int64_t h1_chunks(int64_t N) { return (N + H1_ROWS - 1) / H1_ROWS; }
+static inline H1Groups h1_carve(void *buf, int64_t N, int64_t E) {
+  GsCarver c(buf);
+  H1Groups g;
+  const int64_t nch = h1_chunks(N);
+  g.goff = c.take<int>((size_t)nch + 1);
+  g.bsum = c.take<int>((size_t)((nch + 1 + GS_SCAN_CH - 1) / GS_SCAN_CH + 1));
+  g.gdesc = c.take<int2>((size_t)(N + E / 32 + 1));
+  return g;
+}
+
+template <int NB, bool TRAIN>
+__global__ void __launch_bounds__(256)
+hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
+                 const int *__restrict__ col, const float *__restrict__ inv_deg,
+                 const float *__restrict__ U, const uint16_t *__restrict__ Wp, int64_t N, float scale,
+                 float *__restrict__ out, int64_t out_blk) {
+  static_assert(!TRAIN || NB == 2, "the 64 mask bits of a row cover 64 columns");
+  constexpr int D = H1_DEPTH;
+  const int lane = gs_lane(), c = lane & 31, h = lane >> 5;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row0 = chunk * H1_ROWS;
+  if (row0 >= N) return;
+  const int g0 = goff[chunk], g1 = goff[chunk + 1];
+
+  // B operand: column 32 b + c, k = 8 h .. 8 h + 7 of the three weight planes, for the whole launch
+  bf16x8 wf[NB][3];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      wf[b][pl] = *(const bf16x8 *)(Wp + ((int64_t)pl * 32 * NB + 32 * b + c) * 16 + 8 * h);
+  const float idg = row0 + lane < N && lane < H1_ROWS ? inv_deg[row0 + lane] : 0.f;   // lane k: row k's scale
+
+  float s[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) s[b] = 0.f;
+  // training: which mask word a lane reads (columns with c & 2: the high word, held by the lanes
+  // of the upper half) and which bit of it per column block
+  const int bp_base = 4 * (((c >> 1) & 1) * 32 + 4 * h);
+  const int bit0 = (c & 1) * 16 + (c >> 2);
+  const uint32_t u_lane = 32u * (uint32_t)h;       // byte offset of this lane's half of a 64-byte row
+
+  for (int gb = g0; gb < g1; gb += 64) {
+    // the next 64 descriptors of the chunk, one per lane; handed out by readlane
+    const int nb = g1 - gb < 64 ? g1 - gb : 64;
+    int2 dv = make_int2(0, 0);
+    if (lane < nb) dv = gdesc[gb + lane];
+#define H1_P0(I) __builtin_amdgcn_readlane(dv.x, (I))
+#define H1_META(I) __builtin_amdgcn_readlane(dv.y, (I))
+    // neighbour id of lane c in group I of this block (-1: no such neighbour / no such group)
+#define H1_LOAD_COL(DST, I)                                                                   \
+    {                                                                                         \
+      DST = -1;                                                                               \
+      if ((I) < nb) {                                                                         \
+        const int cnt_ = (H1_META(I) >> 8) & 0xFF;                                            \
+        if (c < cnt_) DST = col[H1_P0(I) + c];                                                \
+      }                                                                                       \
+    }
+#define H1_LOAD_U(Q)                                                                          \
+    {                                                                                         \
+      ua[Q] = (f32x4v){0.f, 0.f, 0.f, 0.f};                                                   \
+      ub[Q] = (f32x4v){0.f, 0.f, 0.f, 0.f};                                                   \
+      if (idn[Q] >= 0) {                                                                      \
+        const char *p_ = (const char *)U + ((uint32_t)idn[Q] * 64u + u_lane);                 \
+        ua[Q] = *(const f32x4v *)p_;                                                          \
+        ub[Q] = *(const f32x4v *)(p_ + 16);                                                   \
+      }                                                                                       \
+    }
+    // The rows u[j] of a group hang on its neighbour ids, and a group's 6 NB MFMAs are far shorter
+    // than a trip to memory: a ring of D groups keeps that many row fetches (and as many id
+    // fetches behind them) in flight per wave.  Slot q computes group i, then fetches the rows
+    // of group i + D (ids fetched a round ago) and the ids of group i + 2 D.
+    int idn[D];
+    f32x4v ua[D], ub[D];
+#pragma unroll
+    for (int q = 0; q < D; ++q) H1_LOAD_COL(idn[q], q)
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+      H1_LOAD_U(q)
+      H1_LOAD_COL(idn[q], q + D)
+    }
+    for (int i0 = 0; i0 < nb; i0 += D) {
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const int i = i0 + q;
+        if (i < nb) {
+          const int meta = H1_META(i);
+          const int cnt = (meta >> 8) & 0xFF;
+          const bool live = c < cnt;
+          f32x4v va = ua[q], vb = ub[q];
+          H1_LOAD_U(q)
+          H1_LOAD_COL(idn[q], i + 2 * D)
+          if (cnt > 0) {
+            // ---- this group: A operand = row of neighbour c, k = 8 h .. 8 h + 7
+            uint32_t mword = 0u;
+            if (TRAIN) mword = live ? __float_as_uint(vb[3]) : 0u;
+            vb[3] = (live && h == 0) ? 1.f : 0.f;      // k = 7: the bias column; k = 15: nothing
+            uint32_t p1[8], p2[8], p3[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = e < 4 ? va[e] : vb[e - 4];
+              p1[e] = __float_as_uint(v) & 0xFFFF0000u;
+              const float r1 = v - __uint_as_float(p1[e]);
+              p2[e] = __float_as_uint(r1) & 0xFFFF0000u;
+              p3[e] = __float_as_uint(r1 - __uint_as_float(p2[e]));
+            }
+            // two high halves into one word: bytes 3:2 of the first operand above those of the second
+#define H1_PK(P, E) __builtin_amdgcn_perm(P[(E) + 1], P[E], 0x07060302u)
+            const u32x4v w1 = {H1_PK(p1, 0), H1_PK(p1, 2), H1_PK(p1, 4), H1_PK(p1, 6)};
+            const u32x4v w2 = {H1_PK(p2, 0), H1_PK(p2, 2), H1_PK(p2, 4), H1_PK(p2, 6)};
+            const u32x4v w3 = {H1_PK(p3, 0), H1_PK(p3, 2), H1_PK(p3, 4), H1_PK(p3, 6)};
+#undef H1_PK
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, w1), a2 = __builtin_bit_cast(bf16x8, w2),
+                         a3 = __builtin_bit_cast(bf16x8, w3);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              f32x16 acc;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+              // smallest terms first, so that they are not rounded away against the big partial sums
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wf[b][0], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][2], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][1], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][0], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][1], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][0], acc, 0, 0, 0);
+              // acc[r] = pre-activation of neighbour (r & 3) + 8 (r >> 2) + 4 h, column 32 b + c
+              float t[4] = {0.f, 0.f, 0.f, 0.f};
+              if (TRAIN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const int nb_ = (r & 3) + 8 * (r >> 2);
+                  const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 4 * nb_, (int)mword);
+                  const int keep = __builtin_amdgcn_sbfe((int)m, bit0 + 8 * b, 1);     // 0 or -1
+                  t[r & 3] += __uint_as_float((uint32_t)keep & __float_as_uint(acc[r]));
+                }
+              } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  // one instruction (v_med3_f32): fmaxf() would first canonicalise the MFMA result with
+                  // a second v_max; inline asm is no option, the hazard recogniser does not see it
+                  // read a register the matrix pipe is still writing
+                  t[r & 3] += __builtin_amdgcn_fmed3f(acc[r], 0.f, __builtin_inff());
+                }
+              }
+              s[b] += (t[0] + t[1]) + (t[2] + t[3]);
+            }
+          }
+          // ---- the row's last group: combine the lane halves, scale, store
+          if (meta & H1_META_LAST) {
+            const int r = meta & 0xFF;
+            const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, idg), r)) * scale;
+            const int64_t row = row0 + r;
+#pragma unroll
+            for (int qq = 0; qq < NB / 2; ++qq) {
+              const float t0 = s[2 * qq] + __shfl_xor(s[2 * qq], 32, 64);
+              const float t1 = s[2 * qq + 1] + __shfl_xor(s[2 * qq + 1], 32, 64);
+              float *dst = out_blk ? out + (int64_t)qq * out_blk + row * 64 + lane
+                                   : out + row * (32 * NB) + 64 * qq + lane;
+              *dst = (h ? t1 : t0) * f;    // lanes 0-31: columns 64 qq + c, lanes 32-63: 64 qq + 32 + c
+              s[2 * qq] = 0.f;
+              s[2 * qq + 1] = 0.f;
+            }
+          }
+        }
+      }
+    }
+#undef H1_P0
+#undef H1_META
+#undef H1_LOAD_COL
+#undef H1_LOAD_U
+  }
+}
+
+constexpr size_t h1_planes_bytes(int64_t Fo) { return (size_t)(3 * Fo * 16) * sizeof(uint16_t); }
+
+}  // namespace
+
+extern "C" size_t gsage_hidden1_groups_bytes(int64_t N, int64_t E) {
+  if (N < 0 || E < 0) return 0;
+  const int64_t nch = h1_chunks(N);
+  return gs_align_up((size_t)(nch + 1) * sizeof(int), 256) +
+         gs_align_up((size_t)((nch + 1 + GS_SCAN_CH - 1) / GS_SCAN_CH + 1) * sizeof(int), 256) +
+         gs_align_up((size_t)(N + E / 32 + 1) * sizeof(int2), 256);
+}
+
+extern "C" int gsage_hidden1_groups_build(const int32_t *rowptr, int64_t N, int64_t E, void *groups,
+                                          size_t groups_bytes, gsage_stream_t stream) {
+  if (N < 0 || E < 0 || !rowptr || !groups) return GSAGE_ERR_INVALID_ARG;
+  if (N >= ((int64_t)1 << 26)) return GSAGE_ERR_UNSUPPORTED;      // 64-byte rows addressed by 32-bit offsets
+  if (groups_bytes < gsage_hidden1_groups_bytes(N, E)) return GSAGE_ERR_WORKSPACE;
+  if (N == 0) return GSAGE_OK;
+  hipStream_t st = gs_stream(stream);
+  const H1Groups g = h1_carve(groups, N, E);
+  const int64_t nch = h1_chunks(N);
+  hipLaunchKernelGGL(h1_groups_count_k, dim3((unsigned)((nch + 1 + 255) / 256)), dim3(256), 0, st, rowptr,
+                     N, nch, g.goff);
+  GSAGE_CHECK_LAUNCH();
+  if (int rc = gs_exclusive_scan(g.goff, nch + 1, g.goff, g.bsum, st)) return rc;
+  hipLaunchKernelGGL(h1_groups_fill_k, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, st, rowptr, N,
+                     nch, (const int *)g.goff, g.gdesc);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}
+
+extern "C" int gsage_segment_gather_hidden1_supported(int64_t Fo, int epilogue) {
+  if (epilogue == GSAGE_EPI_RELU) return (Fo == 64 || Fo == 128 || Fo == 256) ? 1 : 0;
+  if (epilogue == GSAGE_EPI_RELU_DROPOUT) return Fo == 64 ? 1 : 0;
+  return 0;
+}
+
+extern "C" size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t Fo) {
+  if (N < 0 || Fo <= 0) return 0;
+  return gs_align_up((size_t)N * 16 * sizeof(float), 256) + gs_align_up(h1_planes_bytes(Fo), 256);
+}
+
+extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *col,
+                                            const float *inv_deg, const float *agg1, const float *x8,
+                                            const float *w_l, const float *b_l, const float *w_r,
+                                            int64_t N, int64_t Fo, int epilogue, float p,
+                                            const float *h1, const uint64_t *relu_sign, float *out,
+                                            int out_blocked, void *ws, size_t ws_bytes,
+                                            gsage_stream_t stream) {
+  if (N < 0 || E < 0 || !groups || !inv_deg || !agg1 || !x8 || !w_l || !b_l || !w_r || !out || !ws)
+    return GSAGE_ERR_INVALID_ARG;
+  if (N >= ((int64_t)1 << 26)) return GSAGE_ERR_UNSUPPORTED;
+  if (!gsage_segment_gather_hidden1_supported(Fo, epilogue)) return GSAGE_ERR_UNSUPPORTED;
+  const bool train = epilogue == GSAGE_EPI_RELU_DROPOUT;
+  if (train && (!(p >= 0.f && p < 1.f) || (!h1 && !relu_sign))) return GSAGE_ERR_INVALID_ARG;
+  if (out_blocked && Fo % 64 != 0) return GSAGE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)agg1 | (uintptr_t)x8 | (uintptr_t)h1 | (uintptr_t)ws) & 15) != 0) return GSAGE_ERR_UNSUPPORTED;
+  if (ws_bytes < gsage_segment_gather_hidden1_workspace_bytes(N, Fo)) return GSAGE_ERR_WORKSPACE;
+  if (N == 0) return GSAGE_OK;     // (col may be NULL: a graph without edges has nothing to index)
+  hipStream_t st = gs_stream(stream);
+  GsCarver carve(ws);
+  float *U = carve.take<float>((size_t)N * 16);
+  uint16_t *planes = carve.take<uint16_t>((size_t)(3 * Fo * 16));
+  hipLaunchKernelGGL(h1_pack_w_k, dim3(gs_grid(Fo * 16, 256, 16)), dim3(256), 0, st, w_l, b_l, w_r,
+                     (int)Fo, planes);
+  hipLaunchKernelGGL(h1_pack_u_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, agg1, x8, N,
+                     train ? 1 : 0, h1, (const unsigned long long *)relu_sign, U);
+  GSAGE_CHECK_LAUNCH();
+  const unsigned grid = (unsigned)((N + 4 * H1_ROWS - 1) / (4 * H1_ROWS));
+  const H1Groups g = h1_carve(const_cast<void *>(groups), N, E);
+  const float scale = train ? 1.0f / (1.0f - p) : 1.0f;
+  const int64_t blk = out_blocked ? N * 64 : 0;
+#define H1_LAUNCH(NB, TR)                                                                        \
+  hipLaunchKernelGGL((hidden1_gather_k<NB, TR>), dim3(grid), dim3(256), 0, st,                  \
+                     (const int *)g.goff, (const int2 *)g.gdesc, col, inv_deg, (const float *)U, \
+                     (const uint16_t *)planes, N, scale, out, blk)
+  if (train) H1_LAUNCH(2, true);
+  else if (Fo == 64) H1_LAUNCH(2, false);
+  else if (Fo == 128) H1_LAUNCH(4, false);
+  else H1_LAUNCH(8, false);
+#undef H1_LAUNCH
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
+}

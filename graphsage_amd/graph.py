@@ -30,6 +30,21 @@ class GraphCSR:
     n_long: torch.Tensor      # int32 [2]
     status: torch.Tensor      # int32 [1]    device flag word
 
+    def hidden1_groups(self) -> torch.Tensor:
+        """The group index of gsage_segment_gather_hidden1 (rows' neighbours in groups of 32, per
+        chunk of 32 rows), built on first use and kept with the CSR it describes."""
+        g = getattr(self, "_h1_groups", None)
+        if g is None:
+            lib = _lib.load()
+            with torch.cuda.device(self.rowptr.device):
+                nbytes = lib.gsage_hidden1_groups_bytes(self.num_nodes, self.num_edges)
+                g = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.rowptr.device)
+                rc = lib.gsage_hidden1_groups_build(self.rowptr.data_ptr(), self.num_nodes, self.num_edges,
+                                                    g.data_ptr(), nbytes, _lib.stream_handle())
+            _lib.check(rc, "gsage_hidden1_groups_build")
+            object.__setattr__(self, "_h1_groups", g)
+        return g
+
     def in_degree(self) -> torch.Tensor:
         return (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
 

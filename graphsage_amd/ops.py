@@ -118,6 +118,37 @@ def aggregate_mean(graph: GraphCSR, x: torch.Tensor) -> torch.Tensor:
                           long_rows=graph.long_rows, n_long=graph.n_long[0:1])
 
 
+def aggregate_hidden1(graph: GraphCSR, agg1, x8, w_l, b_l, w_r, epilogue, p: float = 0.0,
+                      h1: Optional[torch.Tensor] = None, relu_sign: Optional[torch.Tensor] = None,
+                      out_blocked: bool = False) -> torch.Tensor:
+    """Mean aggregation of the first hidden layer recomputed from the input layer's operands
+    (gsage_segment_gather_hidden1): the same [N, Fo] (or blocked) tensor ``aggregate_mean`` gives
+    on the stored activation, up to fp32 rounding, for a quarter of the line traffic."""
+    lib = _lib.load()
+    N, Fo = x8.size(0), w_l.size(0)
+    dev = x8.device
+    for t, name in ((agg1, "agg1"), (x8, "x8"), (w_l, "w_l"), (w_r, "w_r")):
+        if t.dtype != torch.float32 or t.size(-1) != 8 or not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous float32 with 8 columns (7 features padded)")
+    with torch.cuda.device(dev):
+        out = torch.empty((Fo // 64, N, 64) if out_blocked else (N, Fo), dtype=torch.float32, device=dev)
+        ws_bytes = lib.gsage_segment_gather_hidden1_workspace_bytes(N, Fo)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ev = _timer.bracket(f"segment_gather_hidden1_F{Fo}") if _timer is not None and _timer.enabled else None
+        if ev:
+            ev[0].record()
+        rc = lib.gsage_segment_gather_hidden1(graph.hidden1_groups().data_ptr(), graph.num_edges,
+                                              graph.col.data_ptr(), graph.inv_deg.data_ptr(), agg1.data_ptr(), x8.data_ptr(),
+                                              w_l.data_ptr(), b_l.data_ptr(), w_r.data_ptr(), N, Fo,
+                                              int(epilogue), float(p), _lib.ptr(h1), _lib.ptr(relu_sign),
+                                              out.data_ptr(), int(out_blocked), ws.data_ptr(), ws_bytes,
+                                              _lib.stream_handle())
+        if ev:
+            ev[1].record()
+    _lib.check(rc, "gsage_segment_gather_hidden1")
+    return out
+
+
 # ------------------------------------------------ column-blocked activations (wide inference)
 # A blocked [N, F] activation is F/64 separate [N, 64] tables: tensor shape [F/64, N, 64].  The
 # 256-wide gather over one 10 GB table runs 15 % below the same bytes gathered from 2.56 GB

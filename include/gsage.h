@@ -128,6 +128,42 @@ int gsage_segment_gather_ew(const int32_t *rowptr, const int32_t *col, const flo
                             const int32_t *long_rows, const int32_t *n_long,
                             gsage_stream_t stream);
 
+/* K2 for the layer BEHIND the input layer, recomputed from the input layer's operands.  The rows
+ * PyG gathers there are h1[j] = dropout(relu(W_l1 . agg1[j] + b1 + W_r1 . x[j])) (graphsage.py:
+ * 133-135 feeding the next SAGEConv's propagate): 64..256 floats each, yet functions of the 7
+ * input features of j and their neighbour mean.  This entry point fetches the 64-byte row
+ * [agg1[j] | x[j]] per neighbour instead of the 256 B..1 KB row of h1 (every fabric read is a
+ * 128-byte line: half to an eighth of the line traffic, from a table of N x 64 bytes) and redoes
+ * the 16 -> Fo projection on the matrix cores (bf16 MFMA on the exact three-way split of the fp32
+ * operands, fp32 accumulation):
+ *   out[i,:] = inv_deg[i] * sum_{p in row i} act(W_l1 . agg1[col[p]] + b1 + W_r1 . x8[col[p]])
+ *   agg1, x8 : fp32 [N,8], column 7 of both ZERO (the 7 input features padded to 8; the bias
+ *              rides in that column), w_l / w_r : fp32 [Fo,8] padded alike, b_l [Fo]
+ *   epilogue : GSAGE_EPI_RELU (Fo = 64, 128, 256) or GSAGE_EPI_RELU_DROPOUT (Fo = 64: the 64
+ *              keep-and-positive bits of a row travel in its two padding columns).  Training takes
+ *              the zero pattern of the h1 that was STORED, so both agree on which elements exist:
+ *              relu_sign = the bits gsage_project_fwd_ex left (used if its flag word says they
+ *              were written), else h1 [N,64] is read for h1 > 0; one of the two must be given.
+ *              Values are recomputed, i.e. equal to the stored ones up to fp32 rounding.
+ *   out      : fp32 [N,Fo] row-major, or column-blocked (out_blocked, gsage_project_fwd_blocked)
+ *   ws       : gsage_segment_gather_hidden1_workspace_bytes(N, Fo) bytes (the 64-byte rows and
+ *              the weight planes).
+ *   groups   : the graph's group index, built ONCE per CSR by gsage_hidden1_groups_build into
+ *              gsage_hidden1_groups_bytes(N, E) bytes: every row's neighbours cut into groups of
+ *              32 (the matrix instruction's row count), listed per chunk of 32 rows, so a wave
+ *              walks its chunk without computing where the next group starts.  N < 2^26. */
+size_t gsage_hidden1_groups_bytes(int64_t N, int64_t E);
+int gsage_hidden1_groups_build(const int32_t *rowptr, int64_t N, int64_t E, void *groups,
+                               size_t groups_bytes, gsage_stream_t stream);
+int gsage_segment_gather_hidden1_supported(int64_t Fo, int epilogue);
+size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t Fo);
+int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *col,
+                                 const float *inv_deg, const float *agg1, const float *x8, const float *w_l,
+                                 const float *b_l, const float *w_r, int64_t N, int64_t Fo,
+                                 int epilogue, float p, const float *h1, const uint64_t *relu_sign,
+                                 float *out, int out_blocked, void *ws, size_t ws_bytes,
+                                 gsage_stream_t stream);
+
 /* ------------------------------------------------------------ K3: fused projection
  * Replaces `F.linear(agg, W_l, b_l) + F.linear(x, W_r)` (PyG SAGEConv.forward) fused
  * with F.relu / nn.Dropout (graphsage.py:134-135) or F.normalize (graphsage.py:141-142).

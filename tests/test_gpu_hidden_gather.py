@@ -1,0 +1,116 @@
+"""GPU: gsage_segment_gather_hidden1 -- the aggregation of the first hidden layer recomputed from
+the input layer's operands -- against what it replaces: the plain segment gather over the stored
+activation (PyG: SAGEConv.propagate on h1 = dropout(relu(conv1(x))), graphsage.py:133-135), and
+against the same sum in float64 on the CPU."""
+import pytest
+import torch
+
+from graphsage_amd import _lib
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, fo, deg, seed, feats=7):
+    from graphsage_amd.graph import default_cache
+    from graphsage_amd.synth import powerlaw_graph
+    g = torch.Generator().manual_seed(seed)
+    ei = powerlaw_graph(n, deg, seed=seed)
+    x8 = torch.zeros(n, 8)
+    x8[:, :feats] = torch.rand(n, feats, generator=g) * 2 - 0.5
+    wl = torch.zeros(fo, 8)
+    wr = torch.zeros(fo, 8)
+    wl[:, :feats] = torch.randn(fo, feats, generator=g) / 2
+    wr[:, :feats] = torch.randn(fo, feats, generator=g) / 2
+    b = torch.randn(fo, generator=g) / 4
+    graph = default_cache().get(ei.cuda(), n)
+    return ei, x8, wl, b, wr, graph
+
+
+def _ref64(ei, x8, wl, b, wr, n, act):
+    """float64 on the CPU: mean_j act(W_l mean_k x_k + b + W_r x_j)"""
+    src, dst = ei[0], ei[1]
+    deg = torch.zeros(n, dtype=torch.float64).index_add_(0, dst, torch.ones(ei.size(1), dtype=torch.float64))
+    inv = 1.0 / deg.clamp_min(1.0)
+    x = x8.double()
+    agg1 = torch.zeros(n, 8, dtype=torch.float64).index_add_(0, dst, x[src]) * inv[:, None]
+    h1 = act(agg1 @ wl.double().T + b.double() + x @ wr.double().T)
+    return torch.zeros(n, wl.size(0), dtype=torch.float64).index_add_(0, dst, h1[src]) * inv[:, None], h1
+
+
+@pytest.mark.parametrize("n,deg", [(1, 1), (70, 3), (3000, 12), (20000, 40)])
+@pytest.mark.parametrize("fo", [64, 128, 256])
+def test_eval_matches_the_gather_over_the_stored_activation(n, deg, fo):
+    from graphsage_amd import ops
+    ei, x8, wl, b, wr, graph = _setup(n, fo, deg, seed=n + fo)
+    d = [t.cuda() for t in (x8, wl, b, wr)]
+    agg1 = ops.aggregate_mean(graph, d[0])
+    h1, _ = ops.project_fwd(agg1, d[0], d[1], d[2], d[3], epilogue=_lib.EPI_RELU)
+    want_gpu = ops.aggregate_mean(graph, h1)
+    got = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU)
+    want, _ = _ref64(ei, x8, wl, b, wr, n, torch.relu)
+    assert_close(got, want, what="vs float64")
+    assert_close(got, want_gpu, what="vs the plain gather")
+    # column-blocked output: the same numbers in the other layout
+    gotb = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU, out_blocked=True)
+    assert torch.equal(gotb.permute(1, 0, 2).reshape(n, fo), got)
+
+
+@pytest.mark.parametrize("n,deg", [(1, 1), (333, 5), (5000, 20), (20000, 40)])
+@pytest.mark.parametrize("bits", ["sign", "h1"])
+def test_training_takes_the_zero_pattern_of_the_stored_activation(n, deg, bits):
+    from graphsage_amd import ops
+    p = 0.3
+    ei, x8, wl, b, wr, graph = _setup(n, 64, deg, seed=7 * n)
+    d = [t.cuda() for t in (x8, wl, b, wr)]
+    keep = (torch.rand(n, 64, generator=torch.Generator().manual_seed(n)) >= p).to(torch.uint8)
+    agg1 = ops.aggregate_mean(graph, d[0])
+    h1, _, sign = ops.project_fwd(agg1, d[0], d[1], d[2], d[3], epilogue=_lib.EPI_RELU_DROPOUT,
+                                  keep_mask=keep.cuda(), p=p, want_relu_sign=True)
+    want_gpu = ops.aggregate_mean(graph, h1)
+    got = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU_DROPOUT, p=p,
+                                h1=h1 if bits == "h1" else None, relu_sign=sign if bits == "sign" else None)
+    assert_close(got, want_gpu, what="vs the plain gather")
+    want, _ = _ref64(ei, x8, wl, b, wr, n, lambda v: torch.relu(v) * keep.double() / (1 - p))
+    assert_close(got, want, what="vs float64")
+
+
+def test_isolated_rows_hub_rows_and_duplicate_edges():
+    """a star (one row with 5 000 neighbours: 157 groups), rows without in-edges, a repeated edge"""
+    from graphsage_amd import ops
+    from graphsage_amd.graph import default_cache
+    n = 6000
+    hub = torch.stack([torch.arange(1, 5001), torch.zeros(5000, dtype=torch.int64)])
+    extra = torch.tensor([[0, 0, 7, 7, 5999], [5500, 5500, 5501, 5501, 5999]])      # duplicates, a self loop
+    ei = torch.cat([hub, extra], 1)
+    g = torch.Generator().manual_seed(3)
+    x8 = torch.zeros(n, 8)
+    x8[:, :7] = torch.rand(n, 7, generator=g)
+    wl, wr = torch.zeros(64, 8), torch.zeros(64, 8)
+    wl[:, :7], wr[:, :7] = torch.randn(64, 7, generator=g), torch.randn(64, 7, generator=g)
+    b = torch.randn(64, generator=g)
+    graph = default_cache().get(ei.cuda(), n)
+    d = [t.cuda() for t in (x8, wl, b, wr)]
+    agg1 = ops.aggregate_mean(graph, d[0])
+    got = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU)
+    want, _ = _ref64(ei, x8, wl, b, wr, n, torch.relu)
+    assert_close(got, want)
+    assert torch.count_nonzero(got[1:5000]).item() == 0       # leaves of the star have no in-edges
+
+
+def test_argument_checks():
+    from graphsage_amd import ops
+    lib = _lib.load()
+    assert lib.gsage_segment_gather_hidden1_supported(64, _lib.EPI_RELU_DROPOUT) == 1
+    assert lib.gsage_segment_gather_hidden1_supported(128, _lib.EPI_RELU_DROPOUT) == 0
+    assert lib.gsage_segment_gather_hidden1_supported(256, _lib.EPI_RELU) == 1
+    assert lib.gsage_segment_gather_hidden1_supported(96, _lib.EPI_RELU) == 0
+    assert lib.gsage_segment_gather_hidden1_supported(64, _lib.EPI_L2NORM) == 0
+    ei, x8, wl, b, wr, graph = _setup(100, 64, 4, seed=1)
+    d = [t.cuda() for t in (x8, wl, b, wr)]
+    agg1 = ops.aggregate_mean(graph, d[0])
+    with pytest.raises(ValueError):          # training needs the stored zero pattern
+        ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU_DROPOUT, p=0.3)
+    with pytest.raises(ValueError):          # 7 features padded to 8, nothing else
+        ops.aggregate_hidden1(graph, agg1[:, :7].contiguous(), d[0], d[1], d[2], d[3], _lib.EPI_RELU)
