@@ -33,9 +33,6 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int H1_ROWS = 32;       // destination rows per wave (one trip per wave, in-order dispatch)
-#ifndef H1_DEPTH
-#define H1_DEPTH 1
-#endif
 
 // ---- weight planes: Wc[n][k] = k < 7 ? W_l[n][k] : k == 7 ? b[n] : k < 15 ? W_r[n][k-8] : 0,
 // split into three bf16 planes [3][Fo][16]
@@ -97,28 +94,35 @@ __global__ void __launch_bounds__(256) h1_pack_u_k(const float *__restrict__ agg
   *(f32x4v *)(u + 12) = b1;
 }
 
-// ---- group index: the 32-neighbour groups of every row, cut once per graph.  Row chunk k (rows
-// 32 k .. 32 k + 31, one wave) owns descriptors goff[k] .. goff[k+1]; a descriptor is
-// (p0 = first position in col, meta = row in chunk | count << 8 | last group of its row << 16 |
-// 1 << 17).  A row without neighbours has one descriptor with count 0 (it stores its zero row).
-// With the walk precomputed the wave spends no vector instructions on finding its next group.
-constexpr int H1_META_VALID = 1 << 17, H1_META_LAST = 1 << 16;
+// ---- group index, cut once per graph.  The matrix instruction takes 32 neighbours at a time, a
+// row of the benchmark graphs has 11 at the median: one group per row would leave half the
+// instruction's rows empty.  So a row's neighbours are cut into SLOTS of 8, and a group is any 4
+// consecutive slots of a chunk of 32 destination rows (one wave), whatever rows they belong to: the
+// accumulator registers 4 s .. 4 s + 3 of a lane (both lane halves) are exactly the 8 neighbours of
+// slot s, so a row's sum is taken over register quads.  A slot descriptor is (p = first position in
+// col, meta = count 0..8 | row in chunk << 4 | last slot of its row << 9 | valid << 10); a row
+// without neighbours has one slot with count 0 (it stores its zero row).  Chunk k owns the groups
+// goff[k] .. goff[k+1], its last group padded with invalid slots.
+constexpr int H1_SLOT = 8;
+constexpr int H1_META_LAST = 1 << 9, H1_META_VALID = 1 << 10;
+
+__device__ __forceinline__ int h1_row_slots(int deg) { return deg > 0 ? (deg + H1_SLOT - 1) / H1_SLOT : 1; }
 
 __global__ void __launch_bounds__(256) h1_groups_count_k(const int *__restrict__ rowptr, int64_t N,
                                                          int64_t nchunks, int *__restrict__ counts) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k > nchunks) return;
-  int cnt = 0;
+  int slots = 0;
   if (k < nchunks) {
     const int64_t r0 = k * H1_ROWS, r1 = r0 + H1_ROWS < N ? r0 + H1_ROWS : N;
     int prev = rowptr[r0];
     for (int64_t r = r0; r < r1; ++r) {
-      const int nxt = rowptr[r + 1], deg = nxt - prev;
-      cnt += deg > 0 ? (deg + 31) >> 5 : 1;
+      const int nxt = rowptr[r + 1];
+      slots += h1_row_slots(nxt - prev);
       prev = nxt;
     }
   }
-  counts[k] = cnt;                        // counts[nchunks] = 0: the scan leaves the total there
+  counts[k] = (slots + 3) >> 2;           // counts[nchunks] = 0: the scan leaves the total there
 }
 
 __global__ void __launch_bounds__(256) h1_groups_fill_k(const int *__restrict__ rowptr, int64_t N,
@@ -127,33 +131,38 @@ __global__ void __launch_bounds__(256) h1_groups_fill_k(const int *__restrict__ 
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= nchunks) return;
   const int64_t r0 = k * H1_ROWS, r1 = r0 + H1_ROWS < N ? r0 + H1_ROWS : N;
-  int2 *d = gdesc + goff[k];
+  int2 *d = gdesc + (int64_t)goff[k] * 4;
+  int2 *const end = gdesc + (int64_t)goff[k + 1] * 4;
   int prev = rowptr[r0];
   for (int64_t r = r0; r < r1; ++r) {
     const int nxt = rowptr[r + 1], deg = nxt - prev, rr = (int)(r - r0);
-    if (deg == 0) *d++ = make_int2(prev, rr | H1_META_LAST | H1_META_VALID);
-    for (int off = 0; off < deg; off += 32) {
-      const int left = deg - off;
-      *d++ = make_int2(prev + off, rr | ((left < 32 ? left : 32) << 8) | (left <= 32 ? H1_META_LAST : 0) |
-                                       H1_META_VALID);
+    const int ns = h1_row_slots(deg);
+    for (int q = 0; q < ns; ++q) {
+      const int left = deg - q * H1_SLOT;
+      *d++ = make_int2(prev + q * H1_SLOT, (left < H1_SLOT ? (left > 0 ? left : 0) : H1_SLOT) | (rr << 4) |
+                                           (q == ns - 1 ? H1_META_LAST : 0) | H1_META_VALID);
     }
     prev = nxt;
   }
+  while (d < end) *d++ = make_int2(0, 0);
 }
 
 struct H1Groups {        // carved from the caller's buffer (gsage_hidden1_groups_bytes)
   int *goff;             // nchunks + 1 (+ scan block sums behind it)
   int *bsum;
-  int2 *gdesc;           // at most N + E / 32 descriptors
+  int2 *gdesc;           // 4 slots per group
 };
 static inline int64_t h1_chunks(int64_t N) { return (N + H1_ROWS - 1) / H1_ROWS; }
+// slots <= N + E / 8 (a row of degree d > 0 has ceil(d / 8) <= 1 + d / 8 of them... minus: d / 8 + 1),
+// groups <= slots / 4 + one partly filled group per chunk
+static inline int64_t h1_max_groups(int64_t N, int64_t E) { return (N + E / H1_SLOT) / 4 + h1_chunks(N) + 1; }
 static inline H1Groups h1_carve(void *buf, int64_t N, int64_t E) {
   GsCarver c(buf);
   H1Groups g;
   const int64_t nch = h1_chunks(N);
   g.goff = c.take<int>((size_t)nch + 1);
   g.bsum = c.take<int>((size_t)((nch + 1 + GS_SCAN_CH - 1) / GS_SCAN_CH + 1));
-  g.gdesc = c.take<int2>((size_t)(N + E / 32 + 1));
+  g.gdesc = c.take<int2>((size_t)(4 * h1_max_groups(N, E)));
   return g;
 }
 
@@ -164,7 +173,6 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
                  const float *__restrict__ U, const uint16_t *__restrict__ Wp, int64_t N, float scale,
                  float *__restrict__ out, int64_t out_blk) {
   static_assert(!TRAIN || NB == 2, "the 64 mask bits of a row cover 64 columns");
-  constexpr int D = H1_DEPTH;
   const int lane = gs_lane(), c = lane & 31, h = lane >> 5;
   const int64_t chunk = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row0 = chunk * H1_ROWS;
@@ -188,137 +196,137 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
   const int bp_base = 4 * (((c >> 1) & 1) * 32 + 4 * h);
   const int bit0 = (c & 1) * 16 + (c >> 2);
   const uint32_t u_lane = 32u * (uint32_t)h;       // byte offset of this lane's half of a 64-byte row
+  const int sl = c >> 3, ln = c & 7;               // this lane's slot of a group, its place in the slot
 
-  for (int gb = g0; gb < g1; gb += 64) {
-    // the next 64 descriptors of the chunk, one per lane; handed out by readlane
-    const int nb = g1 - gb < 64 ? g1 - gb : 64;
-    int2 dv = make_int2(0, 0);
-    if (lane < nb) dv = gdesc[gb + lane];
-#define H1_P0(I) __builtin_amdgcn_readlane(dv.x, (I))
-#define H1_META(I) __builtin_amdgcn_readlane(dv.y, (I))
-    // neighbour id of lane c in group I of this block (-1: no such neighbour / no such group)
-#define H1_LOAD_COL(DST, I)                                                                   \
-    {                                                                                         \
-      DST = -1;                                                                               \
-      if ((I) < nb) {                                                                         \
-        const int cnt_ = (H1_META(I) >> 8) & 0xFF;                                            \
-        if (c < cnt_) DST = col[H1_P0(I) + c];                                                \
-      }                                                                                       \
+  // Three loads hang on one another -- slot descriptor, neighbour id, the row u[j] -- so the loop
+  // runs them as a pipeline: while group g is computed, the rows of g + 1, the ids of g + 2 and
+  // the descriptors of g + 3 are in flight.
+#define H1_LOAD_DESC(DST, G)                                                                  \
+  {                                                                                           \
+    DST = make_int2(0, 0);                                                                    \
+    if ((G) < g1) DST = gdesc[(int64_t)(G) * 4 + sl];                                         \
+  }
+#define H1_LOAD_COL(DST, DESC)                                                                \
+  {                                                                                           \
+    DST = -1;                                                                                 \
+    if (ln < ((DESC).y & 15)) DST = col[(DESC).x + ln];                                       \
+  }
+#define H1_LOAD_U(A, B, ID)                                                                   \
+  {                                                                                           \
+    A = (f32x4v){0.f, 0.f, 0.f, 0.f};                                                         \
+    B = (f32x4v){0.f, 0.f, 0.f, 0.f};                                                         \
+    if ((ID) >= 0) {                                                                          \
+      const char *p_ = (const char *)U + ((uint32_t)(ID) * 64u + u_lane);                     \
+      A = *(const f32x4v *)p_;                                                                \
+      B = *(const f32x4v *)(p_ + 16);                                                         \
+    }                                                                                         \
+  }
+  int2 d0, d1, d2, d3;          // descriptors of group g, g + 1, g + 2, g + 3 (this lane's slot)
+  int id1, id2;                 // neighbour ids of g + 1, g + 2
+  f32x4v ua, ub;                // the row of g
+  bool live;
+  {
+    int id0;
+    H1_LOAD_DESC(d0, g0)
+    H1_LOAD_DESC(d1, g0 + 1)
+    H1_LOAD_DESC(d2, g0 + 2)
+    H1_LOAD_COL(id0, d0)
+    H1_LOAD_COL(id1, d1)
+    H1_LOAD_U(ua, ub, id0)
+    live = id0 >= 0;
+  }
+  for (int g = g0; g < g1; ++g) {
+    f32x4v na, nb;
+    H1_LOAD_U(na, nb, id1)
+    H1_LOAD_COL(id2, d2)
+    H1_LOAD_DESC(d3, g + 3)
+    // ---- this group: A operand = row of neighbour c, k = 8 h .. 8 h + 7
+    uint32_t mword = 0u;
+    if (TRAIN) mword = live ? __float_as_uint(ub[3]) : 0u;
+    ub[3] = (live && h == 0) ? 1.f : 0.f;          // k = 7: the bias column; k = 15: nothing
+    uint32_t p1[8], p2[8], p3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = e < 4 ? ua[e] : ub[e - 4];
+      p1[e] = __float_as_uint(v) & 0xFFFF0000u;
+      const float r1 = v - __uint_as_float(p1[e]);
+      p2[e] = __float_as_uint(r1) & 0xFFFF0000u;
+      p3[e] = __float_as_uint(r1 - __uint_as_float(p2[e]));
     }
-#define H1_LOAD_U(Q)                                                                          \
-    {                                                                                         \
-      ua[Q] = (f32x4v){0.f, 0.f, 0.f, 0.f};                                                   \
-      ub[Q] = (f32x4v){0.f, 0.f, 0.f, 0.f};                                                   \
-      if (idn[Q] >= 0) {                                                                      \
-        const char *p_ = (const char *)U + ((uint32_t)idn[Q] * 64u + u_lane);                 \
-        ua[Q] = *(const f32x4v *)p_;                                                          \
-        ub[Q] = *(const f32x4v *)(p_ + 16);                                                   \
-      }                                                                                       \
-    }
-    // The rows u[j] of a group hang on its neighbour ids, and a group's 6 NB MFMAs are far shorter
-    // than a trip to memory: a ring of D groups keeps that many row fetches (and as many id
-    // fetches behind them) in flight per wave.  Slot q computes group i, then fetches the rows
-    // of group i + D (ids fetched a round ago) and the ids of group i + 2 D.
-    int idn[D];
-    f32x4v ua[D], ub[D];
-#pragma unroll
-    for (int q = 0; q < D; ++q) H1_LOAD_COL(idn[q], q)
-#pragma unroll
-    for (int q = 0; q < D; ++q) {
-      H1_LOAD_U(q)
-      H1_LOAD_COL(idn[q], q + D)
-    }
-    for (int i0 = 0; i0 < nb; i0 += D) {
-#pragma unroll
-      for (int q = 0; q < D; ++q) {
-        const int i = i0 + q;
-        if (i < nb) {
-          const int meta = H1_META(i);
-          const int cnt = (meta >> 8) & 0xFF;
-          const bool live = c < cnt;
-          f32x4v va = ua[q], vb = ub[q];
-          H1_LOAD_U(q)
-          H1_LOAD_COL(idn[q], i + 2 * D)
-          if (cnt > 0) {
-            // ---- this group: A operand = row of neighbour c, k = 8 h .. 8 h + 7
-            uint32_t mword = 0u;
-            if (TRAIN) mword = live ? __float_as_uint(vb[3]) : 0u;
-            vb[3] = (live && h == 0) ? 1.f : 0.f;      // k = 7: the bias column; k = 15: nothing
-            uint32_t p1[8], p2[8], p3[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float v = e < 4 ? va[e] : vb[e - 4];
-              p1[e] = __float_as_uint(v) & 0xFFFF0000u;
-              const float r1 = v - __uint_as_float(p1[e]);
-              p2[e] = __float_as_uint(r1) & 0xFFFF0000u;
-              p3[e] = __float_as_uint(r1 - __uint_as_float(p2[e]));
-            }
-            // two high halves into one word: bytes 3:2 of the first operand above those of the second
+    // two high halves into one word: bytes 3:2 of the first operand above those of the second
 #define H1_PK(P, E) __builtin_amdgcn_perm(P[(E) + 1], P[E], 0x07060302u)
-            const u32x4v w1 = {H1_PK(p1, 0), H1_PK(p1, 2), H1_PK(p1, 4), H1_PK(p1, 6)};
-            const u32x4v w2 = {H1_PK(p2, 0), H1_PK(p2, 2), H1_PK(p2, 4), H1_PK(p2, 6)};
-            const u32x4v w3 = {H1_PK(p3, 0), H1_PK(p3, 2), H1_PK(p3, 4), H1_PK(p3, 6)};
+    const u32x4v w1 = {H1_PK(p1, 0), H1_PK(p1, 2), H1_PK(p1, 4), H1_PK(p1, 6)};
+    const u32x4v w2 = {H1_PK(p2, 0), H1_PK(p2, 2), H1_PK(p2, 4), H1_PK(p2, 6)};
+    const u32x4v w3 = {H1_PK(p3, 0), H1_PK(p3, 2), H1_PK(p3, 4), H1_PK(p3, 6)};
 #undef H1_PK
-            const bf16x8 a1 = __builtin_bit_cast(bf16x8, w1), a2 = __builtin_bit_cast(bf16x8, w2),
-                         a3 = __builtin_bit_cast(bf16x8, w3);
+    const bf16x8 a1 = __builtin_bit_cast(bf16x8, w1), a2 = __builtin_bit_cast(bf16x8, w2),
+                 a3 = __builtin_bit_cast(bf16x8, w3);
+    // 64 columns (two blocks) at a time, so that the accumulators and slot sums of a wide layer
+    // never live together
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-              f32x16 acc;
+    for (int bp = 0; bp < NB / 2; ++bp) {
+      float t[2][4];              // per column block: the sums over the 8 neighbours of slot 0..3
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-              // smallest terms first, so that they are not rounded away against the big partial sums
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wf[b][0], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][2], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][1], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][0], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][1], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][0], acc, 0, 0, 0);
-              // acc[r] = pre-activation of neighbour (r & 3) + 8 (r >> 2) + 4 h, column 32 b + c
-              float t[4] = {0.f, 0.f, 0.f, 0.f};
-              if (TRAIN) {
+      for (int bb = 0; bb < 2; ++bb) {
+        const int b = 2 * bp + bb;
+        f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                  const int nb_ = (r & 3) + 8 * (r >> 2);
-                  const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 4 * nb_, (int)mword);
-                  const int keep = __builtin_amdgcn_sbfe((int)m, bit0 + 8 * b, 1);     // 0 or -1
-                  t[r & 3] += __uint_as_float((uint32_t)keep & __float_as_uint(acc[r]));
-                }
-              } else {
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // smallest terms first, so that they are not rounded away against the big partial sums
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wf[b][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][0], acc, 0, 0, 0);
+        // acc[r] = pre-activation of neighbour (r & 3) + 8 (r >> 2) + 4 h, column 32 b + c
+        float v[16];
+        if (TRAIN) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                  // one instruction (v_med3_f32): fmaxf() would first canonicalise the MFMA result with
-                  // a second v_max; inline asm is no option, the hazard recogniser does not see it
-                  // read a register the matrix pipe is still writing
-                  t[r & 3] += __builtin_amdgcn_fmed3f(acc[r], 0.f, __builtin_inff());
-                }
-              }
-              s[b] += (t[0] + t[1]) + (t[2] + t[3]);
-            }
+          for (int r = 0; r < 16; ++r) {
+            const int nb_ = (r & 3) + 8 * (r >> 2);
+            const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 4 * nb_, (int)mword);
+            const int keep = __builtin_amdgcn_sbfe((int)m, bit0 + 8 * b, 1);     // 0 or -1
+            v[r] = __uint_as_float((uint32_t)keep & __float_as_uint(acc[r]));
           }
-          // ---- the row's last group: combine the lane halves, scale, store
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r], 0.f);      // one v_max (-fno-honor-nans)
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[bb][q] = (v[4 * q] + v[4 * q + 1]) + (v[4 * q + 2] + v[4 * q + 3]);
+      }
+      // ---- hand the slot sums to their rows; a row's last slot combines the lane halves and stores
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int meta = __builtin_amdgcn_readlane(d0.y, 8 * q);
+        if (meta & H1_META_VALID) {
+          s[2 * bp] += t[0][q];
+          s[2 * bp + 1] += t[1][q];
           if (meta & H1_META_LAST) {
-            const int r = meta & 0xFF;
+            const int r = (meta >> 4) & 31;
             const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, idg), r)) * scale;
             const int64_t row = row0 + r;
-#pragma unroll
-            for (int qq = 0; qq < NB / 2; ++qq) {
-              const float t0 = s[2 * qq] + __shfl_xor(s[2 * qq], 32, 64);
-              const float t1 = s[2 * qq + 1] + __shfl_xor(s[2 * qq + 1], 32, 64);
-              float *dst = out_blk ? out + (int64_t)qq * out_blk + row * 64 + lane
-                                   : out + row * (32 * NB) + 64 * qq + lane;
-              *dst = (h ? t1 : t0) * f;    // lanes 0-31: columns 64 qq + c, lanes 32-63: 64 qq + 32 + c
-              s[2 * qq] = 0.f;
-              s[2 * qq + 1] = 0.f;
-            }
+            const float t0 = s[2 * bp] + __shfl_xor(s[2 * bp], 32, 64);
+            const float t1 = s[2 * bp + 1] + __shfl_xor(s[2 * bp + 1], 32, 64);
+            float *dst = out_blk ? out + (int64_t)bp * out_blk + row * 64 + lane
+                                 : out + row * (32 * NB) + 64 * bp + lane;
+            *dst = (h ? t1 : t0) * f;      // lanes 0-31: columns 64 bp + c, lanes 32-63: 64 bp + 32 + c
+            s[2 * bp] = 0.f;
+            s[2 * bp + 1] = 0.f;
           }
         }
       }
     }
-#undef H1_P0
-#undef H1_META
+    d0 = d1; d1 = d2; d2 = d3;
+    live = id1 >= 0;
+    id1 = id2;
+    ua = na;
+    ub = nb;
+  }
+#undef H1_LOAD_DESC
 #undef H1_LOAD_COL
 #undef H1_LOAD_U
-  }
 }
 
 constexpr size_t h1_planes_bytes(int64_t Fo) { return (size_t)(3 * Fo * 16) * sizeof(uint16_t); }
@@ -330,7 +338,7 @@ extern "C" size_t gsage_hidden1_groups_bytes(int64_t N, int64_t E) {
   const int64_t nch = h1_chunks(N);
   return gs_align_up((size_t)(nch + 1) * sizeof(int), 256) +
          gs_align_up((size_t)((nch + 1 + GS_SCAN_CH - 1) / GS_SCAN_CH + 1) * sizeof(int), 256) +
-         gs_align_up((size_t)(N + E / 32 + 1) * sizeof(int2), 256);
+         gs_align_up((size_t)(4 * h1_max_groups(N, E)) * sizeof(int2), 256);
 }
 
 extern "C" int gsage_hidden1_groups_build(const int32_t *rowptr, int64_t N, int64_t E, void *groups,
