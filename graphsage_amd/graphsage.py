@@ -63,9 +63,12 @@ class SAGEConv(nn.Module):
 
     def run(self, x: torch.Tensor, graph: GraphCSR, epilogue: int = _lib.EPI_NONE, p: float = 0.0,
             seed: int = 0, keep_mask: Optional[torch.Tensor] = None,
-            force_generic: bool = False, input_layer: bool = True) -> torch.Tensor:
+            force_generic: bool = False, input_layer: bool = True,
+            agg: Optional[torch.Tensor] = None, stash: Optional[dict] = None) -> torch.Tensor:
         """``input_layer``: x is the model's input (constant node features), so its padded copy is
-        worth caching; hidden activations are temporaries and are padded without caching."""
+        worth caching; hidden activations are temporaries and are padded without caching.
+        ``agg``: the layer's neighbour mean computed elsewhere (no gradient wanted for it);
+        ``stash``: filled with this layer's operands for :func:`ops.aggregate_hidden1_from`."""
         w_l, w_r = self.lin_l.weight, self.lin_r.weight
         x_key = x
         width = vector_width(x.size(1))
@@ -75,11 +78,10 @@ class SAGEConv(nn.Module):
             pad = width - x.size(1)
             x = default_cache().padded(x, width, keep=input_layer)
             w_l, w_r = F.pad(w_l, (0, pad)), F.pad(w_r, (0, pad))
-        agg = None
-        if self.cache_aggregation and input_layer and not x_key.requires_grad:
+        if agg is None and self.cache_aggregation and input_layer and not x_key.requires_grad:
             agg = default_cache().aggregated(x_key, x, graph, aggregate_mean)
         return SAGELayerFunction.apply(x, w_l, self.lin_l.bias, w_r, graph, epilogue, p, seed,
-                                       keep_mask, force_generic, agg)
+                                       keep_mask, force_generic, agg, stash)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         graph = default_cache().get(edge_index, x.size(0))
@@ -135,18 +137,28 @@ class GraphSAGE(nn.Module):
             return self._forward_blocked(x, graph)
         p = float(self.dropout_rate)
         training = self.training and p > 0.0
+        # the input layer leaves its operands behind: the layer after it can recompute the rows it
+        # aggregates from them instead of gathering the stored activation (ops.aggregate_hidden1)
+        stash = {} if (len(self.convs) > 1 and not self._force_generic and ops.HIDDEN1_RECOMPUTE) else None
+
+        def agg_for(i):
+            if i == 1 and ops.hidden1_applies(stash, self.in_channels, graph.num_nodes):
+                return ops.aggregate_hidden1_from(graph, stash)
+            return None
+
         for i, conv in enumerate(self.convs[:-1]):
             if training:
                 km = keep_masks[i] if keep_masks is not None else None
                 seed = 0 if km is not None else self._dropout_seed()
                 x = conv.run(x, graph, _lib.EPI_RELU_DROPOUT, p, seed, km, self._force_generic,
-                             input_layer=i == 0)
+                             input_layer=i == 0, agg=agg_for(i), stash=stash if i == 0 else None)
             else:
                 x = conv.run(x, graph, _lib.EPI_RELU, 0.0, 0, None, self._force_generic,
-                             input_layer=i == 0)
+                             input_layer=i == 0, agg=agg_for(i), stash=stash if i == 0 else None)
         epi = _lib.EPI_L2NORM if self.normalize_output else _lib.EPI_NONE
+        last = len(self.convs) - 1
         return self.convs[-1].run(x, graph, epi, 0.0, 0, None, self._force_generic,
-                                  input_layer=len(self.convs) == 1)
+                                  input_layer=last == 0, agg=agg_for(last))
 
     # ---- wide models without autograd: hidden activations kept column-blocked (ops.py)
     def _blocked_inference_applies(self, x: torch.Tensor) -> bool:
@@ -177,7 +189,7 @@ class GraphSAGE(nn.Module):
         x8 = default_cache().padded(_f32(x), 8, keep=True)
         pad = 8 - first.in_channels
         w_l, w_r = F.pad(first.lin_l.weight, (0, pad)), F.pad(first.lin_r.weight, (0, pad))
-        agg = ops.aggregate_mean(graph, x8)
+        agg1 = agg = ops.aggregate_mean(graph, x8)
         # every hidden layer leaves max |h| behind (one word, float bits): the bound the next
         # layer's fp16-split GEMM scales its operands by (the mean of rows of h cannot exceed it),
         # so that GEMM need not make two passes over its 20 GB of input to find it
@@ -185,15 +197,26 @@ class GraphSAGE(nn.Module):
         h, _ = ops.project_fwd_blocked(agg, x8, w_l, first.lin_l.bias, w_r, _lib.EPI_RELU, False, True,
                                        amax_out=amax[0:1])
         del agg
+        # the first wide aggregation: recomputed from [agg1 | x8] (64 bytes per neighbour instead of
+        # the activation's F/64 rows of 256 bytes)
+        stash = dict(agg=agg1, x=x8, w_l=w_l, b_l=first.lin_l.bias, w_r=w_r, sign=None,
+                     epilogue=_lib.EPI_RELU, p=0.0)
+        recompute = ops.hidden1_applies(stash, first.in_channels, graph.num_nodes)
+
+        def aggregate(i, h):
+            if i == 0 and recompute:
+                return ops.aggregate_hidden1_from(graph, stash, out_blocked=True)
+            return ops.aggregate_mean_blocked(graph, h)
+
         for i, conv in enumerate(self.convs[1:-1]):
-            agg = ops.aggregate_mean_blocked(graph, h)
+            agg = aggregate(i, h)
             h, _ = ops.project_fwd_blocked(agg, h, conv.lin_l.weight, conv.lin_l.bias,
                                            conv.lin_r.weight, _lib.EPI_RELU, True, True,
                                            amax_in=amax[i:i + 1], amax_out=amax[i + 1:i + 2])
             del agg
         last = self.convs[-1]
         epi = _lib.EPI_L2NORM if self.normalize_output else _lib.EPI_NONE
-        agg = ops.aggregate_mean_blocked(graph, h)
+        agg = aggregate(len(self.convs) - 2, h)
         out, _ = ops.project_fwd_blocked(agg, h, last.lin_l.weight, last.lin_l.bias,
                                          last.lin_r.weight, epi, True, False, amax_in=amax[-1:])
         return out

@@ -118,6 +118,33 @@ def aggregate_mean(graph: GraphCSR, x: torch.Tensor) -> torch.Tensor:
                           long_rows=graph.long_rows, n_long=graph.n_long[0:1])
 
 
+# The layer behind the input layer aggregates rows that are functions of 14 numbers each: fetch
+# those and redo the projection on the matrix cores instead of gathering the stored activation
+# (gsage_segment_gather_hidden1).  GSAGE_HIDDEN1_RECOMPUTE=0 keeps the plain gather.
+HIDDEN1_RECOMPUTE = os.environ.get("GSAGE_HIDDEN1_RECOMPUTE", "1") != "0"
+
+
+def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int) -> bool:
+    """Can the aggregation of the layer whose forward filled ``stash`` be recomputed?  Its input
+    must be the 7 (or fewer) features padded to 8 columns and its epilogue one the kernel has."""
+    if not HIDDEN1_RECOMPUTE or not stash or in_channels > 7 or num_nodes >= (1 << 26):
+        return False
+    x, w_l = stash["x"], stash["w_l"]
+    if x.size(1) != 8 or w_l.size(1) != 8 or not x.is_cuda:
+        return False
+    if stash["epilogue"] == _lib.EPI_RELU_DROPOUT and stash["sign"] is None:
+        return False          # would have to read the stored activation for its zero pattern
+    return bool(_lib.load().gsage_segment_gather_hidden1_supported(w_l.size(0), int(stash["epilogue"])))
+
+
+def aggregate_hidden1_from(graph: GraphCSR, stash: dict, out_blocked: bool = False) -> torch.Tensor:
+    with torch.no_grad():
+        return aggregate_hidden1(graph, stash["agg"], stash["x"], stash["w_l"].detach().contiguous(),
+                                 stash["b_l"].detach(), stash["w_r"].detach().contiguous(),
+                                 stash["epilogue"], p=stash["p"], relu_sign=stash["sign"],
+                                 out_blocked=out_blocked)
+
+
 def aggregate_hidden1(graph: GraphCSR, agg1, x8, w_l, b_l, w_r, epilogue, p: float = 0.0,
                       h1: Optional[torch.Tensor] = None, relu_sign: Optional[torch.Tensor] = None,
                       out_blocked: bool = False) -> torch.Tensor:
@@ -492,7 +519,7 @@ class SAGELayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_l, b_l, w_r, graph: GraphCSR, epilogue: int, p: float, seed: int,
-                keep_mask, force_generic: bool, agg_cached=None):
+                keep_mask, force_generic: bool, agg_cached=None, stash: Optional[dict] = None):
         x = _f32c(x, "x")
         w_l, b_l, w_r = _f32c(w_l, "lin_l.weight"), _f32c(b_l, "lin_l.bias"), _f32c(w_r, "lin_r.weight")
         if x.dim() != 2 or x.size(0) != graph.num_nodes:
@@ -508,6 +535,9 @@ class SAGELayerFunction(torch.autograd.Function):
                                        alloc_relu_sign=want_sign)
         ctx.graph, ctx.epilogue, ctx.p, ctx.force_generic = graph, epilogue, p, force_generic
         ctx.save_for_backward(x, agg, out, rnorm, w_l, w_r, sign)
+        if stash is not None:
+            # what the next layer's aggregation can be recomputed from (aggregate_hidden1)
+            stash.update(agg=agg, x=x, w_l=w_l, b_l=b_l, w_r=w_r, sign=sign, epilogue=epilogue, p=p)
         return out
 
     @staticmethod
@@ -522,7 +552,7 @@ class SAGELayerFunction(torch.autograd.Function):
             grad_agg, grad_x, gwl, gb, gwr = project_bwd(
                 grad_out, out, rnorm, agg, x, w_l, w_r, None, ctx.epilogue, ctx.p, True,
                 ctx.force_generic)
-            return (grad_x if need_x else None), gwl, gb, gwr, None, None, None, None, None, None, grad_agg
+            return (grad_x if need_x else None), gwl, gb, gwr, None, None, None, None, None, None, grad_agg, None
         live = getattr(grad_out, "_gsage_live", None)
         if (live is not None and need_x and not ctx.force_generic and SKIP_ZERO_ROWS
                 and live.version == grad_out._version and live.num_rows == x.size(0)
@@ -533,7 +563,7 @@ class SAGELayerFunction(torch.autograd.Function):
                 grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p, live)
             grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x,
                                         live_mask=live.mask)
-            return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None
+            return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None
         grad_agg, grad_x, gwl, gb, gwr, nz = project_bwd(
             grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p,
             need_x, ctx.force_generic, want_nz_mask=True, relu_sign=sign)
@@ -541,7 +571,7 @@ class SAGELayerFunction(torch.autograd.Function):
             # grad_agg arrives pre-scaled by inv_deg[row]; gather it over the transposed CSR
             grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x,
                                         nz_mask=nz if SKIP_ZERO_ROWS else None)
-        return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None
+        return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None
 
 
 class SkipGramFunction(torch.autograd.Function):
