@@ -122,6 +122,10 @@ def aggregate_mean(graph: GraphCSR, x: torch.Tensor) -> torch.Tensor:
 # those and redo the projection on the matrix cores instead of gathering the stored activation
 # (gsage_segment_gather_hidden1).  GSAGE_HIDDEN1_RECOMPUTE=0 keeps the plain gather.
 HIDDEN1_RECOMPUTE = os.environ.get("GSAGE_HIDDEN1_RECOMPUTE", "1") != "0"
+# ... from the size on where the stored activation no longer sits in the 256 MB Infinity Cache:
+# below it the plain gather reads its rows from cache and wins (measured on the benchmark graphs:
+# break-even at 1 M nodes x 64 columns in eval mode, 2 M in training, 250-300 k nodes x 128 / 256)
+HIDDEN1_MIN_BYTES = int(os.environ.get("GSAGE_HIDDEN1_MIN_BYTES", str(256 << 20)))
 
 
 def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int) -> bool:
@@ -132,12 +136,19 @@ def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int) -> 
     x, w_l = stash["x"], stash["w_l"]
     if x.size(1) != 8 or w_l.size(1) != 8 or not x.is_cuda:
         return False
-    if stash["epilogue"] == _lib.EPI_RELU_DROPOUT and stash["sign"] is None:
+    training = stash["epilogue"] == _lib.EPI_RELU_DROPOUT
+    if num_nodes * w_l.size(0) * 4 < HIDDEN1_MIN_BYTES * (2 if training else 1):
+        return False
+    if training and stash["sign"] is None:
         return False          # would have to read the stored activation for its zero pattern
     return bool(_lib.load().gsage_segment_gather_hidden1_supported(w_l.size(0), int(stash["epilogue"])))
 
 
+HIDDEN1_STATS = {"used": 0}      # tests / diagnostics
+
+
 def aggregate_hidden1_from(graph: GraphCSR, stash: dict, out_blocked: bool = False) -> torch.Tensor:
+    HIDDEN1_STATS["used"] += 1
     with torch.no_grad():
         return aggregate_hidden1(graph, stash["agg"], stash["x"], stash["w_l"].detach().contiguous(),
                                  stash["b_l"].detach(), stash["w_r"].detach().contiguous(),

@@ -114,3 +114,40 @@ def test_argument_checks():
         ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU_DROPOUT, p=0.3)
     with pytest.raises(ValueError):          # 7 features padded to 8, nothing else
         ops.aggregate_hidden1(graph, agg1[:, :7].contiguous(), d[0], d[1], d[2], d[3], _lib.EPI_RELU)
+
+
+@pytest.mark.parametrize("hidden,layers,train", [(64, 2, True), (64, 2, False), (64, 3, True), (256, 3, False)])
+def test_model_with_the_recomputed_aggregation_equals_the_plain_path(monkeypatch, hidden, layers, train):
+    """GraphSAGE.forward with the second layer's aggregation recomputed (forced on: small graphs
+    keep the plain gather by default) against the same model on the plain path: embeddings, and
+    in training mode every parameter gradient, with the same injected dropout masks."""
+    from graphsage_amd import GraphSAGE, ops
+    from graphsage_amd.synth import memory_features, powerlaw_graph
+    n = 4000
+    ei = powerlaw_graph(n, 14, seed=5).cuda()
+    x = memory_features(n, seed=5).cuda()
+    torch.manual_seed(3)
+    model = GraphSAGE(7, hidden, 64, layers, 0.3 if train else 0.0).cuda()
+    model.train(train)
+    g = torch.Generator().manual_seed(9)
+    masks = [(torch.rand(n, hidden, generator=g) >= 0.3).to(torch.uint8).cuda() for _ in range(layers - 1)] \
+        if train else None
+    gout = torch.randn(n, 64, generator=g).cuda()
+
+    def run(min_bytes, recompute):
+        monkeypatch.setattr(ops, "HIDDEN1_MIN_BYTES", min_bytes)
+        monkeypatch.setattr(ops, "HIDDEN1_RECOMPUTE", recompute)
+        model.zero_grad()
+        before = ops.HIDDEN1_STATS["used"]
+        emb = model(x, ei, keep_masks=masks)
+        used = ops.HIDDEN1_STATS["used"] - before
+        if train:
+            emb.backward(gout)
+        return emb.detach().clone(), [p.grad.clone() for p in model.parameters()] if train else [], used
+
+    emb0, grads0, used0 = run(1 << 60, False)
+    emb1, grads1, used1 = run(0, True)
+    assert used0 == 0 and used1 == 1
+    assert_close(emb1, emb0, what="embeddings")
+    for a, b, (name, _) in zip(grads1, grads0, model.named_parameters()):
+        assert_close(a, b, what=name)
