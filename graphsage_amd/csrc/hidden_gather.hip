@@ -10,7 +10,8 @@
 //
 //   out[i,:] = inv_deg[i] * sum_{p in row i} act( [W_l1 | b1 | W_r1 | 0] . [agg1[j] | 1 | x[j] | 0] ),  j = col[p]
 //
-// One wave per destination row and 32-neighbour group: the 32 rows u[j] are the A operand of
+// One wave per chunk of 64 destination rows; their neighbours are walked in groups of 32 (four
+// slots of 8, see the group index below): the 32 rows u[j] are the A operand of
 // v_mfma_f32_32x32x16_bf16 (K = 16 is exactly the layer's input width, the bias rides in the
 // padding column 7), every fp32 operand as the exact sum of three bf16 parts and the six largest
 // of the nine products issued, smallest first (project.hip, gemm_split_k: fp32-equivalent
@@ -32,7 +33,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
-constexpr int H1_ROWS = 32;       // destination rows per wave (one trip per wave, in-order dispatch)
+#ifndef H1_ROWS_PER_WAVE
+#define H1_ROWS_PER_WAVE 64
+#endif
+constexpr int H1_ROWS = H1_ROWS_PER_WAVE;   // destination rows per wave, at most 64 (one trip per wave, in-order dispatch)
 
 // ---- weight planes: Wc[n][k] = k < 7 ? W_l[n][k] : k == 7 ? b[n] : k < 15 ? W_r[n][k-8] : 0,
 // split into three bf16 planes [3][Fo][16]
@@ -97,14 +101,14 @@ __global__ void __launch_bounds__(256) h1_pack_u_k(const float *__restrict__ agg
 // ---- group index, cut once per graph.  The matrix instruction takes 32 neighbours at a time, a
 // row of the benchmark graphs has 11 at the median: one group per row would leave half the
 // instruction's rows empty.  So a row's neighbours are cut into SLOTS of 8, and a group is any 4
-// consecutive slots of a chunk of 32 destination rows (one wave), whatever rows they belong to: the
+// consecutive slots of a chunk of 64 destination rows (one wave), whatever rows they belong to: the
 // accumulator registers 4 s .. 4 s + 3 of a lane (both lane halves) are exactly the 8 neighbours of
 // slot s, so a row's sum is taken over register quads.  A slot descriptor is (p = first position in
-// col, meta = count 0..8 | row in chunk << 4 | last slot of its row << 9 | valid << 10); a row
+// col, meta = count 0..8 | row in chunk << 4 | last slot of its row << 10 | valid << 11); a row
 // without neighbours has one slot with count 0 (it stores its zero row).  Chunk k owns the groups
 // goff[k] .. goff[k+1], its last group padded with invalid slots.
 constexpr int H1_SLOT = 8;
-constexpr int H1_META_LAST = 1 << 9, H1_META_VALID = 1 << 10;
+constexpr int H1_META_LAST = 1 << 10, H1_META_VALID = 1 << 11;
 
 __device__ __forceinline__ int h1_row_slots(int deg) { return deg > 0 ? (deg + H1_SLOT - 1) / H1_SLOT : 1; }
 
@@ -304,7 +308,7 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
           s[2 * bp] += t[0][q];
           s[2 * bp + 1] += t[1][q];
           if (meta & H1_META_LAST) {
-            const int r = (meta >> 4) & 31;
+            const int r = (meta >> 4) & 63;
             const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, idg), r)) * scale;
             const int64_t row = row0 + r;
             const float t0 = s[2 * bp] + __shfl_xor(s[2 * bp], 32, 64);

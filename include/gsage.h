@@ -150,7 +150,7 @@ int gsage_segment_gather_ew(const int32_t *rowptr, const int32_t *col, const flo
  *              the weight planes).
  *   groups   : the graph's group index, built ONCE per CSR by gsage_hidden1_groups_build into
  *              gsage_hidden1_groups_bytes(N, E) bytes: every row's neighbours cut into groups of
- *              32 (the matrix instruction's row count), listed per chunk of 32 rows, so a wave
+ *              32 (the matrix instruction's row count) out of slots of 8, listed per chunk of 64 rows, so a wave
  *              walks its chunk without computing where the next group starts.  N < 2^26. */
 size_t gsage_hidden1_groups_bytes(int64_t N, int64_t E);
 int gsage_hidden1_groups_build(const int32_t *rowptr, int64_t N, int64_t E, void *groups,
