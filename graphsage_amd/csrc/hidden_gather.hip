@@ -333,163 +333,6 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
 #undef H1_LOAD_U
 }
 
-// ---- K7h: the input layer's weight gradients straight from the layer-2 backward, without the
-// dense gradient of the hidden activation in between.  PyG's backward (graphsage.py:133-138 under
-// autograd) first scatters d(loss)/d(agg2) back over the edges into d(loss)/d(h1) [N, 64] and then
-// contracts that with the input layer's operands.  With g_i = inv_deg[i] * d(loss)/d(agg2)[i]
-// (non-zero on the rows i the batch touched), r_j = the root-path gradient of row j and m_j the
-// keep-and-positive bits of h1[j] (the bits in u[j], see above):
-//   dW[c][k] = sum_{live i} sum_{j in N(i)} m_j[c] g_i[c] u_j[k]  +  sum_{live j} m_j[c] r_j[c] u_j[k]
-// with u_j = [agg1[j] | 1 | x[j] | 0], so column 7 of dW is the bias gradient.  Every live edge
-// (i <- j) costs the 64-byte row u[j] (one line) where the transposed gather fetches the
-// 256-byte row g_i per edge of j (two lines), and nothing of size N x 64 is written or re-read.
-// v_mfma_f32_16x16x4_f32 takes its K dimension from the lane GROUP (lane >> 4): four neighbours
-// sit in the four 16-lane groups of a wave, lane (group n, f) holds u[n][f] as the B operand
-// and m_n[c] g_i[c] for c = 16 t + f as the A operand of tile t -- exact fp32 products, no
-// transposes, no operand splitting; the 64 x 16 result stays in 16 accumulator registers per
-// lane for the whole launch.
-constexpr int H1B_GRID = 256 * 8;                 // persistent workgroups
-constexpr int H1B_SLAB = 64 * 16;                 // dW[c][k] of one workgroup
-
-__global__ void __launch_bounds__(256)
-hidden1_dweights_k(const int *__restrict__ rows, const int *__restrict__ n_rows, int rows_cap,
-                   const int *__restrict__ rowptr, const int *__restrict__ col,
-                   const float *__restrict__ U, const float *__restrict__ gagg,
-                   const float *__restrict__ groot, float inv_keep, float *__restrict__ slabs) {
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  __shared__ float red[4][16][64];
-  const int lane = gs_lane(), wave = threadIdx.x >> 6;
-  const int f = lane & 15, ng = lane >> 4;
-  const int n = *n_rows < rows_cap ? *n_rows : rows_cap;
-  const int bit0 = (f & 1) * 16 + (f >> 2);       // bit of column 16 t + f in its mask word: bit0 + 4 t
-  const int lo_lane = 4 * ((lane & 48) | 7), hi_lane = 4 * ((lane & 48) | 15);   // bpermute addresses
-  // The matrix pipe's accumulation is not what sums the launch: chains of MFMAs into one
-  // accumulator showed a rounding bias that grows with the chain (same-sign terms, as the bias
-  // gradient of a hub row has them: 4e-6 of the largest gradient in the parity test, seven times
-  // the error of the weight columns).  So a chain is at most 36 neighbours long: the accumulators
-  // are added to the running total `tot` (vector adds, round to nearest) every four steps of a
-  // row and at its end.
-  f32x4 acc[1][4], tot[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-#define H1B_FLUSH()                                                                           \
-  _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
-    tot[t] += acc[0][t];                                                                      \
-    acc[0][t] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                  \
-  }
-
-  // one quad: lane group ng holds neighbour row `id` (-1: none) and the gradient vector `vec`
-#define H1B_QUAD(SET, UVAL, VALID, VEC)                                                       \
-  {                                                                                           \
-    const int ub_ = __float_as_int(UVAL);                                                     \
-    const int mlo_ = __builtin_amdgcn_ds_bpermute(lo_lane, ub_);                              \
-    const int mhi_ = __builtin_amdgcn_ds_bpermute(hi_lane, ub_);                              \
-    const int w_ = (f & 2) ? mhi_ : mlo_;                                                     \
-    const float b_ = f == 7 ? ((VALID) ? 1.f : 0.f) : (f == 15 ? 0.f : (UVAL));               \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                           \
-      const int keep_ = __builtin_amdgcn_sbfe(w_, bit0 + 4 * t, 1);                           \
-      const float a_ = __int_as_float(keep_ & __float_as_int((VEC)[t]));                      \
-      acc[SET][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, acc[SET][t], 0, 0, 0);       \
-    }                                                                                         \
-  }
-#ifdef H1B_CAP
-#define H1B_CAP_STMT if (p1 > p0 + H1B_CAP) p1 = p0 + H1B_CAP;
-#else
-#define H1B_CAP_STMT
-#endif
-#define H1B_ROW(SET, R)                                                                       \
-  {                                                                                           \
-    const int i = __builtin_amdgcn_readlane(iv, (R));                                         \
-    const int p0 = __builtin_amdgcn_readlane(p0v, (R));                                       \
-    int p1 = __builtin_amdgcn_readlane(p1v, (R));                                             \
-    H1B_CAP_STMT                                                                              \
-    /* neighbour ids and rows of the first two quads, the row's own operands */              \
-    int ida = p0 + ng < p1 ? col[p0 + ng] : -1;                                               \
-    int idb = p0 + 4 + ng < p1 ? col[p0 + 4 + ng] : -1;                                       \
-    float vg[4], vr[4];                                                                       \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                           \
-      vg[t] = gagg[(int64_t)i * 64 + 16 * t + f];                                             \
-      vr[t] = groot[(int64_t)i * 64 + 16 * t + f];                                            \
-    }                                                                                         \
-    const float uself = ng == 0 ? U[(int64_t)i * 16 + f] : 0.f;                               \
-    float ua = 0.f, ub = 0.f;                                                                 \
-    if (ida >= 0) ua = U[(int64_t)ida * 16 + f];                                              \
-    if (idb >= 0) ub = U[(int64_t)idb * 16 + f];                                              \
-    /* the root path: the row itself as the only neighbour of a quad, with its own vector */  \
-    H1B_QUAD(SET, uself, ng == 0, vr)                                                         \
-    int step_ = 0;                                                                            \
-    for (int p = p0; p < p1; p += 8, ++step_) {                                               \
-      if ((step_ & 3) == 3) H1B_FLUSH()                                                       \
-      /* one step ahead: ids, then rows */                                                    \
-      const int q = p + 8 + ng;                                                               \
-      const int nida = q < p1 ? col[q] : -1;                                                  \
-      const int nidb = q + 4 < p1 ? col[q + 4] : -1;                                          \
-      const bool va = ida >= 0, vb = idb >= 0;                                                \
-      const float ca = ua, cb = ub;                                                           \
-      ua = 0.f; ub = 0.f;                                                                     \
-      if (nida >= 0) ua = U[(int64_t)nida * 16 + f];                                          \
-      if (nidb >= 0) ub = U[(int64_t)nidb * 16 + f];                                          \
-      ida = nida; idb = nidb;                                                                 \
-      H1B_QUAD(SET, ca, va, vg)                                                               \
-      H1B_QUAD(SET, cb, vb, vg)                                                               \
-    }                                                                                         \
-    H1B_FLUSH()                                                                               \
-  }
-
-  const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
-  for (int base = gwave * 64; base < n; base += nwaves * 64) {
-    // this wave's next 64 live rows, one per lane
-    const int nb = n - base < 64 ? n - base : 64;
-    int iv = 0, p0v = 0, p1v = 0;
-    if (lane < nb) {
-      iv = rows[base + lane];
-      p0v = rowptr[iv];
-      p1v = rowptr[iv + 1];
-    }
-    for (int r = 0; r < nb; ++r) H1B_ROW(0, r)
-  }
-#undef H1B_ROW
-#undef H1B_QUAD
-#undef H1B_FLUSH
-  // acc[t][r] of lane l = dW[c = 16 t + 4 (l >> 4) + r][k = l & 15]; the workgroup's four waves
-  // are summed in wave order, the workgroups by h1_dweights_reduce_k in workgroup order
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][4 * t + r][lane] = tot[t][r] * inv_keep;
-  __syncthreads();
-  float *slab = slabs + (int64_t)blockIdx.x * H1B_SLAB;
-  for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-    const int q = e >> 6, l = e & 63;
-    const float v = ((red[0][q][l] + red[1][q][l]) + red[2][q][l]) + red[3][q][l];
-    const int c = 16 * (q >> 2) + 4 * (l >> 4) + (q & 3);
-    slab[c * 16 + (l & 15)] = v;
-  }
-}
-
-__global__ void __launch_bounds__(256)
-h1_dweights_reduce_k(const float *__restrict__ slabs, int nslab, float *__restrict__ gwl,
-                     float *__restrict__ gb, float *__restrict__ gwr) {
-  __shared__ float red[4][64];
-  const int lane = gs_lane(), wave = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + lane;           // element c * 16 + k of the 64 x 16 result
-  float s = 0.f;
-  for (int b = wave; b < nslab; b += 4) s += slabs[(int64_t)b * H1B_SLAB + e];
-  red[wave][lane] = s;
-  __syncthreads();
-  if (wave == 0) {
-    const float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-    const int c = e >> 4, k = e & 15;
-    if (k < 7) gwl[c * 8 + k] = v;
-    else if (k == 7) { gb[c] = v; gwl[c * 8 + 7] = 0.f; }      // the padding column's gradient is zero
-    else if (k < 15) gwr[c * 8 + (k - 8)] = v;
-    else gwr[c * 8 + 7] = 0.f;
-  }
-}
-
 constexpr size_t h1_planes_bytes(int64_t Fo) { return (size_t)(3 * Fo * 16) * sizeof(uint16_t); }
 
 }  // namespace
@@ -574,32 +417,3 @@ extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }
-
-extern "C" size_t gsage_hidden1_dweights_workspace_bytes(void) {
-  return (size_t)H1B_GRID * H1B_SLAB * sizeof(float);
-}
-
-extern "C" int gsage_hidden1_dweights(const int32_t *live_rows, const int32_t *n_live, int64_t live_cap,
-                                      const int32_t *rowptr, const int32_t *col, const float *u_rows,
-                                      const float *grad_agg, const float *grad_root, int64_t N, float p,
-                                      float *grad_w_l, float *grad_b, float *grad_w_r, void *ws,
-                                      size_t ws_bytes, gsage_stream_t stream) {
-  if (N < 0 || live_cap < 0 || !live_rows || !n_live || !rowptr || !u_rows || !grad_agg || !grad_root ||
-      !grad_w_l || !grad_b || !grad_w_r || !ws)
-    return GSAGE_ERR_INVALID_ARG;
-  if (!(p >= 0.f && p < 1.f)) return GSAGE_ERR_INVALID_ARG;
-  if (N >= ((int64_t)1 << 26) || live_cap >= ((int64_t)1 << 31)) return GSAGE_ERR_UNSUPPORTED;
-  if (ws_bytes < gsage_hidden1_dweights_workspace_bytes()) return GSAGE_ERR_WORKSPACE;
-  hipStream_t st = gs_stream(stream);
-  float *slabs = (float *)ws;
-  // a fixed grid whatever the batch: every workgroup writes its slab (zeros when it had no rows),
-  // so the sum below has the same terms in the same order on every call
-  hipLaunchKernelGGL(hidden1_dweights_k, dim3(H1B_GRID), dim3(256), 0, st, live_rows, n_live,
-                     (int)live_cap, rowptr, col, u_rows, grad_agg, grad_root, 1.0f / (1.0f - p), slabs);
-  GSAGE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(h1_dweights_reduce_k, dim3(H1B_SLAB / 64), dim3(256), 0, st, (const float *)slabs,
-                     H1B_GRID, grad_w_l, grad_b, grad_w_r);
-  GSAGE_CHECK_LAUNCH();
-  return GSAGE_OK;
-}
-

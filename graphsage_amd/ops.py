@@ -156,36 +156,9 @@ def aggregate_hidden1_from(graph: GraphCSR, stash: dict, out_blocked: bool = Fal
                                  out_blocked=out_blocked)
 
 
-def hidden1_dweights(graph: GraphCSR, u_rows: torch.Tensor, grad_agg, grad_root, live: "LiveRows",
-                     p: float):
-    """The input layer's (grad_w_l [64,8], grad_b [64], grad_w_r [64,8]) from the layer-2 backward's
-    outputs on the live rows (gsage_hidden1_dweights); ``u_rows`` = the workspace the forward's
-    :func:`aggregate_hidden1` returned with ``return_ws``."""
-    lib = _lib.load()
-    dev = grad_agg.device
-    N = graph.num_nodes
-    with torch.cuda.device(dev):
-        f32 = dict(dtype=torch.float32, device=dev)
-        gwl, gb, gwr = torch.empty(64, 8, **f32), torch.empty(64, **f32), torch.empty(64, 8, **f32)
-        ws_bytes = lib.gsage_hidden1_dweights_workspace_bytes()
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        ev = _timer.bracket("hidden1_dweights") if _timer is not None and _timer.enabled else None
-        if ev:
-            ev[0].record()
-        rc = lib.gsage_hidden1_dweights(live.rows.data_ptr(), live.n_rows.data_ptr(), live.cap,
-                                        graph.rowptr.data_ptr(), graph.col.data_ptr(), u_rows.data_ptr(),
-                                        grad_agg.data_ptr(), grad_root.data_ptr(), N, float(p),
-                                        gwl.data_ptr(), gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(),
-                                        ws_bytes, _lib.stream_handle())
-        if ev:
-            ev[1].record()
-    _lib.check(rc, "gsage_hidden1_dweights")
-    return gwl, gb, gwr
-
-
 def aggregate_hidden1(graph: GraphCSR, agg1, x8, w_l, b_l, w_r, epilogue, p: float = 0.0,
                       h1: Optional[torch.Tensor] = None, relu_sign: Optional[torch.Tensor] = None,
-                      out_blocked: bool = False, return_ws: bool = False):
+                      out_blocked: bool = False) -> torch.Tensor:
     """Mean aggregation of the first hidden layer recomputed from the input layer's operands
     (gsage_segment_gather_hidden1): the same [N, Fo] (or blocked) tensor ``aggregate_mean`` gives
     on the stored activation, up to fp32 rounding, for a quarter of the line traffic."""
@@ -211,7 +184,7 @@ def aggregate_hidden1(graph: GraphCSR, agg1, x8, w_l, b_l, w_r, epilogue, p: flo
         if ev:
             ev[1].record()
     _lib.check(rc, "gsage_segment_gather_hidden1")
-    return (out, ws) if return_ws else out
+    return out
 
 
 # ------------------------------------------------ column-blocked activations (wide inference)

@@ -164,27 +164,6 @@ int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *c
                                  float *out, int out_blocked, void *ws, size_t ws_bytes,
                                  gsage_stream_t stream);
 
-/* The input layer's weight gradients straight from the backward of the layer behind it, for the
- * training step in which gsage_segment_gather_hidden1 ran forward.  Autograd (graphsage.py:133-138)
- * scatters d(loss)/d(agg2) over the edges into the dense d(loss)/d(h1) [N,64], applies relu'/
- * dropout', and contracts that with [agg1 | x].  Here, with the rows the batch touched listed
- * (gsage_touched_rows) and u_rows = the 64-byte rows + mask bits the forward call left at the START
- * of its workspace:
- *   dW[c][k] = sum_{live i} sum_{j in N(i)} m_j[c] grad_agg[i][c] u_j[k] + sum_{live j} m_j[c] grad_root[j][c] u_j[k]
- *   grad_agg  : fp32 [N,64], d(loss)/d(agg2) ALREADY scaled by inv_deg (gsage_project_bwd_rows with
- *               agg_scale), valid on the live rows only;  grad_root : fp32 [N,64], the root-path
- *               gradient (grad_x of the same call), valid on the live rows only
- *   rowptr/col: the in-edge CSR (the forward's orientation);  p: the dropout rate of the forward
- *   grad_w_l / grad_w_r [64,8] (padding column zero), grad_b [64]: overwritten; summed in a fixed
- *   order (bitwise reproducible).  ws: gsage_hidden1_dweights_workspace_bytes() bytes.
- * One 128-byte line per live edge instead of two, no [N,64] gradient written or re-read. */
-size_t gsage_hidden1_dweights_workspace_bytes(void);
-int gsage_hidden1_dweights(const int32_t *live_rows, const int32_t *n_live, int64_t live_cap,
-                           const int32_t *rowptr, const int32_t *col, const float *u_rows,
-                           const float *grad_agg, const float *grad_root, int64_t N, float p,
-                           float *grad_w_l, float *grad_b, float *grad_w_r, void *ws, size_t ws_bytes,
-                           gsage_stream_t stream);
-
 /* ------------------------------------------------------------ K3: fused projection
  * Replaces `F.linear(agg, W_l, b_l) + F.linear(x, W_r)` (PyG SAGEConv.forward) fused
  * with F.relu / nn.Dropout (graphsage.py:134-135) or F.normalize (graphsage.py:141-142).

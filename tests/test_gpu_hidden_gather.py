@@ -151,53 +151,3 @@ def test_model_with_the_recomputed_aggregation_equals_the_plain_path(monkeypatch
     assert_close(emb1, emb0, what="embeddings")
     for a, b, (name, _) in zip(grads1, grads0, model.named_parameters()):
         assert_close(a, b, what=name)
-
-
-@pytest.mark.parametrize("n,deg,b", [(300, 4, 40), (5000, 20, 600), (40000, 30, 3000)])
-def test_input_layer_weight_gradients_without_the_dense_hidden_gradient(n, deg, b):
-    """gsage_hidden1_dweights against the path it replaces: masked transposed gather into the dense
-    d(loss)/d(h1), then the first layer's dW kernel with its relu'/dropout' bits."""
-    from graphsage_amd import ops
-    p = 0.3
-    ei, x8, wl, bias, wr, graph = _setup(n, 64, deg, seed=3 * n)
-    d = [t.cuda() for t in (x8, wl, bias, wr)]
-    agg1 = ops.aggregate_mean(graph, d[0])
-    h1, _, sign = ops.project_fwd(agg1, d[0], d[1], d[2], d[3], epilogue=_lib.EPI_RELU_DROPOUT, p=p, seed=11,
-                                  want_relu_sign=True)
-    _, ws = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU_DROPOUT, p=p,
-                                  relu_sign=sign, return_ws=True)
-    g = torch.Generator().manual_seed(n)
-    t = torch.randint(0, n, (b,), generator=g).cuda()
-    c = torch.randint(0, n, (b,), generator=g).cuda()
-    neg = torch.randint(0, n, (b, 5), generator=g).cuda()
-    live = ops.touched_rows(t, c, neg, n)
-    rows = live.rows[: int(live.n_rows.item())].long()
-    # gradients that exist on the live rows only; everything else poisoned
-    gagg = torch.full((n, 64), float("nan"), device="cuda")
-    groot = torch.full((n, 64), float("nan"), device="cuda")
-    gagg[rows] = torch.randn(rows.numel(), 64, generator=g).cuda() * graph.inv_deg[rows, None]
-    groot[rows] = torch.randn(rows.numel(), 64, generator=g).cuda()
-    gwl, gb, gwr = ops.hidden1_dweights(graph, ws, gagg, groot, live, p)
-    # the path it replaces
-    grad_h1 = ops.aggregate_mean_bwd(graph, gagg, prescaled=True, add_to=groot.clone(), live_mask=live.mask)
-    ref = ops.project_bwd(grad_h1, h1, None, agg1, d[0], d[1], d[3], None, _lib.EPI_RELU_DROPOUT, p, False,
-                          relu_sign=sign)
-    # (two float32 summations of the same +-1-sized terms in different orders: each carries its own
-    # rounding, so the floor is doubled here; the float64 comparison below keeps the usual bar)
-    assert_close(gwl, ref[2], floor=5e-6, what="grad_w_l")
-    assert_close(gb, ref[3], floor=5e-6, what="grad_b")
-    assert_close(gwr, ref[4], floor=5e-6, what="grad_w_r")
-    # and in float64 on the CPU
-    keep = (h1 > 0).double().cpu()
-    gh = torch.zeros(n, 64, dtype=torch.float64)
-    ga = torch.zeros(n, 64, dtype=torch.float64)
-    ga[rows.cpu()] = gagg[rows].double().cpu()
-    gh[rows.cpu()] = groot[rows].double().cpu()
-    gh.index_add_(0, ei[0], ga[ei[1]])
-    g1 = gh * keep / (1 - p)
-    assert_close(gwl[:, :7], (g1.T @ agg1.double().cpu())[:, :7], what="grad_w_l vs float64")
-    assert_close(gwr[:, :7], (g1.T @ x8.double())[:, :7], what="grad_w_r vs float64")
-    assert_close(gb, g1.sum(0), what="grad_b vs float64")
-    # twice the same call: the same bits
-    again = ops.hidden1_dweights(graph, ws, gagg, groot, live, p)
-    assert all(torch.equal(a, b_) for a, b_ in zip((gwl, gb, gwr), again))
