@@ -104,3 +104,30 @@ def test_round2_entry_points_validate_before_touching_the_device():
     assert lib.gsage_skipgram_fwd_noalloc(None, 4, 64, None, None, None, (1 << 24) + 1, 5, 5.0, 8.0, 40.0,
                                           None, None, None) == -5
     assert b"no-alloc" in lib.gsage_error_string(-5)
+
+
+def test_recompute_gather_and_range_entry_points_validate_before_touching_the_device():
+    from graphsage_amd import _lib
+    lib = _lib.load()
+    # which shapes the recomputed aggregation takes
+    sup = lib.gsage_segment_gather_hidden1_supported
+    assert sup(64, _lib.EPI_RELU) == 1 and sup(128, _lib.EPI_RELU) == 1 and sup(256, _lib.EPI_RELU) == 1
+    assert sup(64, _lib.EPI_RELU_DROPOUT) == 1 and sup(128, _lib.EPI_RELU_DROPOUT) == 0   # 64 mask bits per row
+    assert sup(96, _lib.EPI_RELU) == 0 and sup(64, _lib.EPI_NONE) == 0 and sup(64, _lib.EPI_L2NORM) == 0
+    # sizes: the 64-byte rows + weight planes; the group index (<= N + E/8 slots of 8 bytes + offsets)
+    n, e = 10_000_000, 200_000_000
+    assert lib.gsage_segment_gather_hidden1_workspace_bytes(n, 64) >= n * 64
+    assert lib.gsage_segment_gather_hidden1_workspace_bytes(-1, 64) == 0
+    g = lib.gsage_hidden1_groups_bytes(n, e)
+    assert (n + e // 8) * 8 <= g <= 2 * (n + e // 8) * 8
+    assert lib.gsage_hidden1_groups_bytes(-1, 0) == 0
+    # null pointers, unsupported shapes, rows beyond the 32-bit row offsets: refused, nothing launched
+    assert lib.gsage_hidden1_groups_build(None, 10, 10, None, 0, None) == -1
+    args = [None] * 8
+    assert lib.gsage_segment_gather_hidden1(None, 0, *args[:7], 10, 64, _lib.EPI_RELU, 0.0, None, None,
+                                            None, 0, None, 0, None) == -1
+    # gsage_project_fwd_range: eval epilogues only, in and out words must differ
+    assert lib.gsage_project_fwd_range_supported(8, 256, _lib.EPI_RELU) == 1
+    assert lib.gsage_project_fwd_range_supported(64, 64, _lib.EPI_RELU) == 0
+    assert lib.gsage_project_fwd_range(None, None, None, None, None, 10, 256, 256, _lib.EPI_RELU_DROPOUT,
+                                       None, None, None, 0, 0, None, None, None) == -2
