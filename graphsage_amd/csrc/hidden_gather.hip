@@ -107,10 +107,54 @@ __global__ void __launch_bounds__(256) h1_pack_u_k(const float *__restrict__ agg
 // col, meta = count 0..8 | row in chunk << 4 | last slot of its row << 10 | valid << 11); a row
 // without neighbours has one slot with count 0 (it stores its zero row).  Chunk k owns the groups
 // goff[k] .. goff[k+1], its last group padded with invalid slots.
+//
+// HUB rows (more than H1_HUB_T neighbours) stay out of their chunk's list: a chunk is walked by one
+// wave, and a 50 000-neighbour row in it keeps that wave busy for milliseconds while the rest of
+// the launch has long finished (measured at C4: 5.4 ms, against 4.5 ms on the same graph with the
+// degrees capped at 512).  A hub row is cut into PIECES of H1_PIECE neighbours (32 groups, about
+// the length of an ordinary chunk); the first H1_HUB_WAVES waves of the launch walk the piece list
+// -- dispatched first, so the long rows overlap everything else -- and leave one unscaled partial
+// row per piece, which h1_hub_combine_k adds up in piece order (fixed => reproducible) and scales.
+// A piece's slot descriptors are not stored: they follow from (first position, length).
 constexpr int H1_SLOT = 8;
 constexpr int H1_META_LAST = 1 << 10, H1_META_VALID = 1 << 11;
+#ifndef H1_HUB_T_
+#define H1_HUB_T_ 1024
+#endif
+#ifndef H1_PIECE_
+#define H1_PIECE_ 1024
+#endif
+#ifndef H1_HUB_WAVES_
+#define H1_HUB_WAVES_ 8192
+#endif
+constexpr int H1_HUB_T = H1_HUB_T_;
+constexpr int H1_PIECE = H1_PIECE_;              // a multiple of 32 (whole groups)
+constexpr int H1_HUB_WAVES = H1_HUB_WAVES_;      // a multiple of the 4 waves of a workgroup
 
-__device__ __forceinline__ int h1_row_slots(int deg) { return deg > 0 ? (deg + H1_SLOT - 1) / H1_SLOT : 1; }
+__device__ __forceinline__ int h1_row_slots(int deg) {
+  return deg > H1_HUB_T ? 0 : deg > 0 ? (deg + H1_SLOT - 1) / H1_SLOT : 1;
+}
+
+// hub rows -> hubs[h] = (row, first piece, pieces, 0), pieces[i] = (first position in col, length);
+// cnt[0] = pieces, cnt[1] = hub rows (zeroed before the launch).  The order the rows land in is
+// not fixed (atomics), the results do not depend on it: a row's pieces are consecutive and in order.
+__global__ void __launch_bounds__(256) h1_hub_list_k(const int *__restrict__ rowptr, int64_t N,
+                                                     int *__restrict__ cnt, int4 *__restrict__ hubs,
+                                                     int64_t hub_cap, int2 *__restrict__ pieces,
+                                                     int64_t piece_cap) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= N) return;
+  const int p0 = rowptr[r], deg = rowptr[r + 1] - p0;
+  if (deg <= H1_HUB_T) return;
+  const int np = (deg + H1_PIECE - 1) / H1_PIECE;
+  const int base = atomicAdd(cnt, np), h = atomicAdd(cnt + 1, 1);
+  if (h >= hub_cap || (int64_t)base + np > piece_cap) return;     // cannot happen (caps are bounds)
+  hubs[h] = make_int4((int)r, base, np, 0);
+  for (int k = 0; k < np; ++k) {
+    const int left = deg - k * H1_PIECE;
+    pieces[base + k] = make_int2(p0 + k * H1_PIECE, left < H1_PIECE ? left : H1_PIECE);
+  }
+}
 
 __global__ void __launch_bounds__(256) h1_groups_count_k(const int *__restrict__ rowptr, int64_t N,
                                                          int64_t nchunks, int *__restrict__ counts) {
@@ -155,6 +199,11 @@ struct H1Groups {        // carved from the caller's buffer (gsage_hidden1_group
   int *goff;             // nchunks + 1 (+ scan block sums behind it)
   int *bsum;
   int2 *gdesc;           // 4 slots per group
+  int *hcnt;             // [0] pieces, [1] hub rows
+  int4 *hubs;
+  int2 *pieces;
+  int64_t hub_cap, piece_cap;
+  size_t bytes;
 };
 static inline int64_t h1_chunks(int64_t N) { return (N + H1_ROWS - 1) / H1_ROWS; }
 // slots <= N + E / 8 (a row of degree d > 0 has ceil(d / 8) <= 1 + d / 8 of them... minus: d / 8 + 1),
@@ -167,21 +216,33 @@ static inline H1Groups h1_carve(void *buf, int64_t N, int64_t E) {
   g.goff = c.take<int>((size_t)nch + 1);
   g.bsum = c.take<int>((size_t)((nch + 1 + GS_SCAN_CH - 1) / GS_SCAN_CH + 1));
   g.gdesc = c.take<int2>((size_t)(4 * h1_max_groups(N, E)));
+  // a hub row has more than H1_HUB_T neighbours and ceil(deg / H1_PIECE) <= deg / H1_PIECE + 1 pieces
+  g.hub_cap = E / H1_HUB_T + 1;
+  g.piece_cap = E / H1_PIECE + g.hub_cap;
+  g.hcnt = c.take<int>(4);
+  g.hubs = c.take<int4>((size_t)g.hub_cap);
+  g.pieces = c.take<int2>((size_t)g.piece_cap);
+  g.bytes = c.off;
   return g;
 }
+static inline int64_t h1_piece_cap(int64_t E) { return E / H1_PIECE + E / H1_HUB_T + 1; }
 
 template <int NB, bool TRAIN>
 __global__ void __launch_bounds__(256)
 hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
                  const int *__restrict__ col, const float *__restrict__ inv_deg,
                  const float *__restrict__ U, const uint16_t *__restrict__ Wp, int64_t N, float scale,
-                 float *__restrict__ out, int64_t out_blk) {
+                 float *__restrict__ out, int64_t out_blk, const int2 *__restrict__ pieces,
+                 const int *__restrict__ hcnt, float *__restrict__ part) {
   static_assert(!TRAIN || NB == 2, "the 64 mask bits of a row cover 64 columns");
   const int lane = gs_lane(), c = lane & 31, h = lane >> 5;
-  const int64_t chunk = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row0 = chunk * H1_ROWS;
-  if (row0 >= N) return;
-  const int g0 = goff[chunk], g1 = goff[chunk + 1];
+  // the first H1_HUB_WAVES waves walk the pieces of the hub rows (a wave takes piece w, w +
+  // H1_HUB_WAVES, ... and ends when the list does), every other wave one chunk of H1_ROWS rows
+  int64_t item = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool hub = item < H1_HUB_WAVES;
+  const int n_pieces = hub ? hcnt[0] : 0;
+  if (!hub) item -= H1_HUB_WAVES;
+  if (hub ? item >= n_pieces : item * H1_ROWS >= N) return;
 
   // B operand: column 32 b + c, k = 8 h .. 8 h + 7 of the three weight planes, for the whole launch
   bf16x8 wf[NB][3];
@@ -190,25 +251,51 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
       wf[b][pl] = *(const bf16x8 *)(Wp + ((int64_t)pl * 32 * NB + 32 * b + c) * 16 + 8 * h);
-  const float idg = row0 + lane < N && lane < H1_ROWS ? inv_deg[row0 + lane] : 0.f;   // lane k: row k's scale
 
-  float s[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) s[b] = 0.f;
   // training: which mask word a lane reads (columns with c & 2: the high word, held by the lanes
   // of the upper half) and which bit of it per column block
   const int bp_base = 4 * (((c >> 1) & 1) * 32 + 4 * h);
   const int bit0 = (c & 1) * 16 + (c >> 2);
   const uint32_t u_lane = 32u * (uint32_t)h;       // byte offset of this lane's half of a 64-byte row
   const int sl = c >> 3, ln = c & 7;               // this lane's slot of a group, its place in the slot
+  // a piece's partial row is stored like row `piece` of an unblocked [pieces, 32 NB] table
+  float *const o_base = hub ? part : out;
+  const int64_t o_blk = hub ? 0 : out_blk;
 
-  // Three loads hang on one another -- slot descriptor, neighbour id, the row u[j] -- so the loop
-  // runs them as a pipeline: while group g is computed, the rows of g + 1, the ids of g + 2 and
-  // the descriptors of g + 3 are in flight.
+  for (;;) {
+    // ---- this wave's item: a chunk (rows row0 .. row0 + H1_ROWS, groups g0 .. g1 of the index) or a
+    // piece (one run of `plen` neighbours from position pfirst of col, groups 0 .. g1)
+    const int64_t row0 = hub ? item : item * H1_ROWS;
+    int g0 = 0, g1, pfirst = 0, plen = 0;
+    float idg = 0.f;                                 // lane k: the scale of row k of the chunk
+    if (hub) {
+      const int2 pc = pieces[item];
+      pfirst = __builtin_amdgcn_readfirstlane(pc.x);
+      plen = __builtin_amdgcn_readfirstlane(pc.y);
+      g1 = (plen + 31) >> 5;
+    } else {
+      g0 = goff[item];
+      g1 = goff[item + 1];
+      idg = row0 + lane < N && lane < H1_ROWS ? inv_deg[row0 + lane] : 0.f;
+    }
+    float s[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s[b] = 0.f;
+
+    // Three loads hang on one another -- slot descriptor, neighbour id, the row u[j] -- so the loop
+    // runs them as a pipeline: while group g is computed, the rows of g + 1, the ids of g + 2 and
+    // the descriptors of g + 3 are in flight.  (A piece's descriptors are arithmetic.)
 #define H1_LOAD_DESC(DST, G)                                                                  \
   {                                                                                           \
     DST = make_int2(0, 0);                                                                    \
-    if ((G) < g1) DST = gdesc[(int64_t)(G) * 4 + sl];                                         \
+    if (hub) {                                                                                \
+      const int left_ = plen - 8 * (4 * (G) + sl);                                            \
+      if (left_ > 0)                                                                          \
+        DST = make_int2(pfirst + 8 * (4 * (G) + sl),                                          \
+                        (left_ < 8 ? left_ : 8) | (left_ <= 8 ? H1_META_LAST : 0) | H1_META_VALID); \
+    } else if ((G) < g1) {                                                                    \
+      DST = gdesc[(int64_t)(G) * 4 + sl];                                                     \
+    }                                                                                         \
   }
 #define H1_LOAD_COL(DST, DESC)                                                                \
   {                                                                                           \
@@ -225,112 +312,140 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
       B = *(const f32x4v *)(p_ + 16);                                                         \
     }                                                                                         \
   }
-  int2 d0, d1, d2, d3;          // descriptors of group g, g + 1, g + 2, g + 3 (this lane's slot)
-  int id1, id2;                 // neighbour ids of g + 1, g + 2
-  f32x4v ua, ub;                // the row of g
-  bool live;
-  {
-    int id0;
-    H1_LOAD_DESC(d0, g0)
-    H1_LOAD_DESC(d1, g0 + 1)
-    H1_LOAD_DESC(d2, g0 + 2)
-    H1_LOAD_COL(id0, d0)
-    H1_LOAD_COL(id1, d1)
-    H1_LOAD_U(ua, ub, id0)
-    live = id0 >= 0;
-  }
-  for (int g = g0; g < g1; ++g) {
-    f32x4v na, nb;
-    H1_LOAD_U(na, nb, id1)
-    H1_LOAD_COL(id2, d2)
-    H1_LOAD_DESC(d3, g + 3)
-    // ---- this group: A operand = row of neighbour c, k = 8 h .. 8 h + 7
-    uint32_t mword = 0u;
-    if (TRAIN) mword = live ? __float_as_uint(ub[3]) : 0u;
-    ub[3] = (live && h == 0) ? 1.f : 0.f;          // k = 7: the bias column; k = 15: nothing
-    uint32_t p1[8], p2[8], p3[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float v = e < 4 ? ua[e] : ub[e - 4];
-      p1[e] = __float_as_uint(v) & 0xFFFF0000u;
-      const float r1 = v - __uint_as_float(p1[e]);
-      p2[e] = __float_as_uint(r1) & 0xFFFF0000u;
-      p3[e] = __float_as_uint(r1 - __uint_as_float(p2[e]));
+    int2 d0, d1, d2, d3;          // descriptors of group g, g + 1, g + 2, g + 3 (this lane's slot)
+    int id1, id2;                 // neighbour ids of g + 1, g + 2
+    f32x4v ua, ub;                // the row of g
+    bool live;
+    {
+      int id0;
+      H1_LOAD_DESC(d0, g0)
+      H1_LOAD_DESC(d1, g0 + 1)
+      H1_LOAD_DESC(d2, g0 + 2)
+      H1_LOAD_COL(id0, d0)
+      H1_LOAD_COL(id1, d1)
+      H1_LOAD_U(ua, ub, id0)
+      live = id0 >= 0;
     }
-    // two high halves into one word: bytes 3:2 of the first operand above those of the second
+    for (int g = g0; g < g1; ++g) {
+      f32x4v na, nb;
+      H1_LOAD_U(na, nb, id1)
+      H1_LOAD_COL(id2, d2)
+      H1_LOAD_DESC(d3, g + 3)
+      // ---- this group: A operand = row of neighbour c, k = 8 h .. 8 h + 7
+      uint32_t mword = 0u;
+      if (TRAIN) mword = live ? __float_as_uint(ub[3]) : 0u;
+      ub[3] = (live && h == 0) ? 1.f : 0.f;          // k = 7: the bias column; k = 15: nothing
+      uint32_t p1[8], p2[8], p3[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? ua[e] : ub[e - 4];
+        p1[e] = __float_as_uint(v) & 0xFFFF0000u;
+        const float r1 = v - __uint_as_float(p1[e]);
+        p2[e] = __float_as_uint(r1) & 0xFFFF0000u;
+        p3[e] = __float_as_uint(r1 - __uint_as_float(p2[e]));
+      }
+      // two high halves into one word: bytes 3:2 of the first operand above those of the second
 #define H1_PK(P, E) __builtin_amdgcn_perm(P[(E) + 1], P[E], 0x07060302u)
-    const u32x4v w1 = {H1_PK(p1, 0), H1_PK(p1, 2), H1_PK(p1, 4), H1_PK(p1, 6)};
-    const u32x4v w2 = {H1_PK(p2, 0), H1_PK(p2, 2), H1_PK(p2, 4), H1_PK(p2, 6)};
-    const u32x4v w3 = {H1_PK(p3, 0), H1_PK(p3, 2), H1_PK(p3, 4), H1_PK(p3, 6)};
+      const u32x4v w1 = {H1_PK(p1, 0), H1_PK(p1, 2), H1_PK(p1, 4), H1_PK(p1, 6)};
+      const u32x4v w2 = {H1_PK(p2, 0), H1_PK(p2, 2), H1_PK(p2, 4), H1_PK(p2, 6)};
+      const u32x4v w3 = {H1_PK(p3, 0), H1_PK(p3, 2), H1_PK(p3, 4), H1_PK(p3, 6)};
 #undef H1_PK
-    const bf16x8 a1 = __builtin_bit_cast(bf16x8, w1), a2 = __builtin_bit_cast(bf16x8, w2),
-                 a3 = __builtin_bit_cast(bf16x8, w3);
-    // 64 columns (two blocks) at a time, so that the accumulators and slot sums of a wide layer
-    // never live together
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, w1), a2 = __builtin_bit_cast(bf16x8, w2),
+                   a3 = __builtin_bit_cast(bf16x8, w3);
+      // 64 columns (two blocks) at a time, so that the accumulators and slot sums of a wide layer
+      // never live together
 #pragma unroll
-    for (int bp = 0; bp < NB / 2; ++bp) {
-      float t[2][4];              // per column block: the sums over the 8 neighbours of slot 0..3
+      for (int bp = 0; bp < NB / 2; ++bp) {
+        float t[2][4];              // per column block: the sums over the 8 neighbours of slot 0..3
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const int b = 2 * bp + bb;
-        f32x16 acc;
+        for (int bb = 0; bb < 2; ++bb) {
+          const int b = 2 * bp + bb;
+          f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // smallest terms first, so that they are not rounded away against the big partial sums
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wf[b][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][0], acc, 0, 0, 0);
-        // acc[r] = pre-activation of neighbour (r & 3) + 8 (r >> 2) + 4 h, column 32 b + c
-        float v[16];
-        if (TRAIN) {
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          // smallest terms first, so that they are not rounded away against the big partial sums
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wf[b][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][0], acc, 0, 0, 0);
+          // acc[r] = pre-activation of neighbour (r & 3) + 8 (r >> 2) + 4 h, column 32 b + c
+          float v[16];
+          if (TRAIN) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int nb_ = (r & 3) + 8 * (r >> 2);
-            const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 4 * nb_, (int)mword);
-            const int keep = __builtin_amdgcn_sbfe((int)m, bit0 + 8 * b, 1);     // 0 or -1
-            v[r] = __uint_as_float((uint32_t)keep & __float_as_uint(acc[r]));
+            for (int r = 0; r < 16; ++r) {
+              const int nb_ = (r & 3) + 8 * (r >> 2);
+              const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 4 * nb_, (int)mword);
+              const int keep = __builtin_amdgcn_sbfe((int)m, bit0 + 8 * b, 1);     // 0 or -1
+              v[r] = __uint_as_float((uint32_t)keep & __float_as_uint(acc[r]));
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r], 0.f);      // one v_max (-fno-honor-nans)
           }
-        } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r], 0.f);      // one v_max (-fno-honor-nans)
+          for (int q = 0; q < 4; ++q) t[bb][q] = (v[4 * q] + v[4 * q + 1]) + (v[4 * q + 2] + v[4 * q + 3]);
         }
+        // ---- hand the slot sums to their rows; a row's last slot combines the lane halves and stores
+        // (a piece: its one "row" is the partial of the piece, left unscaled)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[bb][q] = (v[4 * q] + v[4 * q + 1]) + (v[4 * q + 2] + v[4 * q + 3]);
-      }
-      // ---- hand the slot sums to their rows; a row's last slot combines the lane halves and stores
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int meta = __builtin_amdgcn_readlane(d0.y, 8 * q);
-        if (meta & H1_META_VALID) {
-          s[2 * bp] += t[0][q];
-          s[2 * bp + 1] += t[1][q];
-          if (meta & H1_META_LAST) {
-            const int r = (meta >> 4) & 63;
-            const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, idg), r)) * scale;
-            const int64_t row = row0 + r;
-            const float t0 = s[2 * bp] + __shfl_xor(s[2 * bp], 32, 64);
-            const float t1 = s[2 * bp + 1] + __shfl_xor(s[2 * bp + 1], 32, 64);
-            float *dst = out_blk ? out + (int64_t)bp * out_blk + row * 64 + lane
-                                 : out + row * (32 * NB) + 64 * bp + lane;
-            *dst = (h ? t1 : t0) * f;      // lanes 0-31: columns 64 bp + c, lanes 32-63: 64 bp + 32 + c
-            s[2 * bp] = 0.f;
-            s[2 * bp + 1] = 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const int meta = __builtin_amdgcn_readlane(d0.y, 8 * q);
+          if (meta & H1_META_VALID) {
+            s[2 * bp] += t[0][q];
+            s[2 * bp + 1] += t[1][q];
+            if (meta & H1_META_LAST) {
+              const int r = (meta >> 4) & 63;
+              const float f = hub ? 1.f
+                                  : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, idg), r)) * scale;
+              const int64_t row = row0 + r;
+              const float t0 = s[2 * bp] + __shfl_xor(s[2 * bp], 32, 64);
+              const float t1 = s[2 * bp + 1] + __shfl_xor(s[2 * bp + 1], 32, 64);
+              float *dst = o_blk ? o_base + (int64_t)bp * o_blk + row * 64 + lane
+                                 : o_base + row * (32 * NB) + 64 * bp + lane;
+              *dst = (h ? t1 : t0) * f;      // lanes 0-31: columns 64 bp + c, lanes 32-63: 64 bp + 32 + c
+              s[2 * bp] = 0.f;
+              s[2 * bp + 1] = 0.f;
+            }
           }
         }
       }
+      d0 = d1; d1 = d2; d2 = d3;
+      live = id1 >= 0;
+      id1 = id2;
+      ua = na;
+      ub = nb;
     }
-    d0 = d1; d1 = d2; d2 = d3;
-    live = id1 >= 0;
-    id1 = id2;
-    ua = na;
-    ub = nb;
-  }
 #undef H1_LOAD_DESC
 #undef H1_LOAD_COL
 #undef H1_LOAD_U
+    if (!hub) return;
+    item += H1_HUB_WAVES;
+    if (item >= n_pieces) return;
+  }
+}
+
+// hub rows: the sum of the row's pieces, in piece order, times inv_deg * scale.  One wave per row.
+__global__ void __launch_bounds__(256)
+h1_hub_combine_k(const int4 *__restrict__ hubs, const int *__restrict__ hcnt,
+                 const float *__restrict__ part, const float *__restrict__ inv_deg, float scale,
+                 int Fo, float *__restrict__ out, int64_t out_blk) {
+  const int lane = gs_lane();
+  const int n_hubs = hcnt[1];
+  const int nwaves = gridDim.x * 4;
+  for (int hb = blockIdx.x * 4 + (threadIdx.x >> 6); hb < n_hubs; hb += nwaves) {
+    const int4 e = hubs[hb];
+    const int64_t row = e.x;
+    const float f = inv_deg[row] * scale;
+    for (int cb = 0; cb < Fo; cb += 64) {
+      float acc = 0.f;
+      const float *src = part + (int64_t)e.y * Fo + cb + lane;
+      for (int k = 0; k < e.z; ++k) acc += src[(int64_t)k * Fo];
+      float *dst = out_blk ? out + (int64_t)(cb >> 6) * out_blk + row * 64 + lane : out + row * Fo + cb + lane;
+      *dst = acc * f;
+    }
+  }
 }
 
 constexpr size_t h1_planes_bytes(int64_t Fo) { return (size_t)(3 * Fo * 16) * sizeof(uint16_t); }
@@ -339,10 +454,7 @@ constexpr size_t h1_planes_bytes(int64_t Fo) { return (size_t)(3 * Fo * 16) * si
 
 extern "C" size_t gsage_hidden1_groups_bytes(int64_t N, int64_t E) {
   if (N < 0 || E < 0) return 0;
-  const int64_t nch = h1_chunks(N);
-  return gs_align_up((size_t)(nch + 1) * sizeof(int), 256) +
-         gs_align_up((size_t)((nch + 1 + GS_SCAN_CH - 1) / GS_SCAN_CH + 1) * sizeof(int), 256) +
-         gs_align_up((size_t)(4 * h1_max_groups(N, E)) * sizeof(int2), 256);
+  return h1_carve(nullptr, N, E).bytes;
 }
 
 extern "C" int gsage_hidden1_groups_build(const int32_t *rowptr, int64_t N, int64_t E, void *groups,
@@ -361,6 +473,10 @@ extern "C" int gsage_hidden1_groups_build(const int32_t *rowptr, int64_t N, int6
   hipLaunchKernelGGL(h1_groups_fill_k, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, st, rowptr, N,
                      nch, (const int *)g.goff, g.gdesc);
   GSAGE_CHECK_LAUNCH();
+  if (!gs_zero_async(g.hcnt, 4 * sizeof(int), st)) return GSAGE_ERR_LAUNCH;
+  hipLaunchKernelGGL(h1_hub_list_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, rowptr, N, g.hcnt,
+                     g.hubs, g.hub_cap, g.pieces, g.piece_cap);
+  GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }
 
@@ -370,9 +486,11 @@ extern "C" int gsage_segment_gather_hidden1_supported(int64_t Fo, int epilogue) 
   return 0;
 }
 
-extern "C" size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t Fo) {
-  if (N < 0 || Fo <= 0) return 0;
-  return gs_align_up((size_t)N * 16 * sizeof(float), 256) + gs_align_up(h1_planes_bytes(Fo), 256);
+extern "C" size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t E, int64_t Fo) {
+  if (N < 0 || E < 0 || Fo <= 0) return 0;
+  // the 64-byte rows, the weight planes, one partial row per piece of a hub row
+  return gs_align_up((size_t)N * 16 * sizeof(float), 256) + gs_align_up(h1_planes_bytes(Fo), 256) +
+         gs_align_up((size_t)h1_piece_cap(E) * (size_t)Fo * sizeof(float), 256);
 }
 
 extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *col,
@@ -390,30 +508,35 @@ extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const
   if (train && (!(p >= 0.f && p < 1.f) || (!h1 && !relu_sign))) return GSAGE_ERR_INVALID_ARG;
   if (out_blocked && Fo % 64 != 0) return GSAGE_ERR_UNSUPPORTED;
   if ((((uintptr_t)agg1 | (uintptr_t)x8 | (uintptr_t)h1 | (uintptr_t)ws) & 15) != 0) return GSAGE_ERR_UNSUPPORTED;
-  if (ws_bytes < gsage_segment_gather_hidden1_workspace_bytes(N, Fo)) return GSAGE_ERR_WORKSPACE;
+  if (ws_bytes < gsage_segment_gather_hidden1_workspace_bytes(N, E, Fo)) return GSAGE_ERR_WORKSPACE;
   if (N == 0) return GSAGE_OK;     // (col may be NULL: a graph without edges has nothing to index)
   hipStream_t st = gs_stream(stream);
   GsCarver carve(ws);
   float *U = carve.take<float>((size_t)N * 16);
   uint16_t *planes = carve.take<uint16_t>((size_t)(3 * Fo * 16));
+  float *part = carve.take<float>((size_t)h1_piece_cap(E) * (size_t)Fo);
   hipLaunchKernelGGL(h1_pack_w_k, dim3(gs_grid(Fo * 16, 256, 16)), dim3(256), 0, st, w_l, b_l, w_r,
                      (int)Fo, planes);
   hipLaunchKernelGGL(h1_pack_u_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, agg1, x8, N,
                      train ? 1 : 0, h1, (const unsigned long long *)relu_sign, U);
   GSAGE_CHECK_LAUNCH();
-  const unsigned grid = (unsigned)((N + 4 * H1_ROWS - 1) / (4 * H1_ROWS));
+  const unsigned grid = (unsigned)((N + 4 * H1_ROWS - 1) / (4 * H1_ROWS)) + H1_HUB_WAVES / 4;
   const H1Groups g = h1_carve(const_cast<void *>(groups), N, E);
   const float scale = train ? 1.0f / (1.0f - p) : 1.0f;
   const int64_t blk = out_blocked ? N * 64 : 0;
 #define H1_LAUNCH(NB, TR)                                                                        \
   hipLaunchKernelGGL((hidden1_gather_k<NB, TR>), dim3(grid), dim3(256), 0, st,                  \
                      (const int *)g.goff, (const int2 *)g.gdesc, col, inv_deg, (const float *)U, \
-                     (const uint16_t *)planes, N, scale, out, blk)
+                     (const uint16_t *)planes, N, scale, out, blk, (const int2 *)g.pieces,          \
+                     (const int *)g.hcnt, part)
   if (train) H1_LAUNCH(2, true);
   else if (Fo == 64) H1_LAUNCH(2, false);
   else if (Fo == 128) H1_LAUNCH(4, false);
   else H1_LAUNCH(8, false);
 #undef H1_LAUNCH
+  GSAGE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(h1_hub_combine_k, dim3(256), dim3(256), 0, st, (const int4 *)g.hubs, (const int *)g.hcnt,
+                     (const float *)part, inv_deg, scale, (int)Fo, out, blk);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }

@@ -146,17 +146,19 @@ int gsage_segment_gather_ew(const int32_t *rowptr, const int32_t *col, const flo
  *              were written), else h1 [N,64] is read for h1 > 0; one of the two must be given.
  *              Values are recomputed, i.e. equal to the stored ones up to fp32 rounding.
  *   out      : fp32 [N,Fo] row-major, or column-blocked (out_blocked, gsage_project_fwd_blocked)
- *   ws       : gsage_segment_gather_hidden1_workspace_bytes(N, Fo) bytes (the 64-byte rows and
- *              the weight planes).
+ *   ws       : gsage_segment_gather_hidden1_workspace_bytes(N, E, Fo) bytes (the 64-byte rows, the
+ *              weight planes, one partial row per 1 024 neighbours of a hub row).
  *   groups   : the graph's group index, built ONCE per CSR by gsage_hidden1_groups_build into
  *              gsage_hidden1_groups_bytes(N, E) bytes: every row's neighbours cut into groups of
  *              32 (the matrix instruction's row count) out of slots of 8, listed per chunk of 64 rows, so a wave
- *              walks its chunk without computing where the next group starts.  N < 2^26. */
+ *              walks its chunk without computing where the next group starts.  Rows with more than
+ *              1 024 neighbours are listed apart, in pieces of 1 024 that other waves sum (added up
+ *              in piece order: results do not depend on scheduling).  N < 2^26. */
 size_t gsage_hidden1_groups_bytes(int64_t N, int64_t E);
 int gsage_hidden1_groups_build(const int32_t *rowptr, int64_t N, int64_t E, void *groups,
                                size_t groups_bytes, gsage_stream_t stream);
 int gsage_segment_gather_hidden1_supported(int64_t Fo, int epilogue);
-size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t Fo);
+size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t E, int64_t Fo);
 int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *col,
                                  const float *inv_deg, const float *agg1, const float *x8, const float *w_l,
                                  const float *b_l, const float *w_r, int64_t N, int64_t Fo,

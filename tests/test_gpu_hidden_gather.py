@@ -99,6 +99,42 @@ def test_isolated_rows_hub_rows_and_duplicate_edges():
     assert torch.count_nonzero(got[1:5000]).item() == 0       # leaves of the star have no in-edges
 
 
+@pytest.mark.parametrize("fo,train", [(64, False), (64, True), (256, False)])
+def test_rows_around_the_hub_threshold_are_cut_into_pieces(fo, train):
+    """rows of 1 023 .. 3 000 neighbours among ordinary ones: above 1 024 a row is summed in pieces
+    of 1 024 by other waves and put together afterwards (1 025 = a full piece and one neighbour)"""
+    from graphsage_amd import ops
+    from graphsage_amd.graph import default_cache
+    n, p = 9000, 0.3
+    g = torch.Generator().manual_seed(11)
+    degs = {5: 1023, 64: 1024, 65: 1025, 700: 2048, 701: 3000, 8999: 1500}
+    parts = [torch.stack([torch.randint(0, n, (d,), generator=g), torch.full((d,), r)]) for r, d in degs.items()]
+    parts.append(torch.randint(0, n, (2, 40000), generator=g))
+    ei = torch.cat(parts, 1)
+    x8 = torch.zeros(n, 8)
+    x8[:, :7] = torch.rand(n, 7, generator=g) * 2 - 0.5
+    wl, wr = torch.zeros(fo, 8), torch.zeros(fo, 8)
+    wl[:, :7], wr[:, :7] = torch.randn(fo, 7, generator=g) / 2, torch.randn(fo, 7, generator=g) / 2
+    b = torch.randn(fo, generator=g) / 4
+    graph = default_cache().get(ei.cuda(), n)
+    d = [t.cuda() for t in (x8, wl, b, wr)]
+    agg1 = ops.aggregate_mean(graph, d[0])
+    if train:
+        keep = (torch.rand(n, fo, generator=g) >= p).to(torch.uint8)
+        _, _, sign = ops.project_fwd(agg1, d[0], d[1], d[2], d[3], epilogue=_lib.EPI_RELU_DROPOUT,
+                                     keep_mask=keep.cuda(), p=p, want_relu_sign=True)
+        got = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU_DROPOUT, p=p, relu_sign=sign)
+        want, _ = _ref64(ei, x8, wl, b, wr, n, lambda v: torch.relu(v) * keep.double() / (1 - p))
+    else:
+        got = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU)
+        want, _ = _ref64(ei, x8, wl, b, wr, n, torch.relu)
+        gotb = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU, out_blocked=True)
+        assert torch.equal(gotb.permute(1, 0, 2).reshape(n, fo), got)
+    assert_close(got, want, what="vs float64")
+    again = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU) if not train else got
+    assert torch.equal(again, got)            # piece order is fixed: bitwise reproducible
+
+
 def test_argument_checks():
     from graphsage_amd import ops
     lib = _lib.load()

@@ -26,7 +26,8 @@ def timed(fn, reps=5):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     widths = [int(a) for a in sys.argv[2:]] or [64, 256]
-    ei = powerlaw_graph(n, 20, seed=42, device="cuda")
+    md = os.environ.get("PROBE_MAX_DEGREE")
+    ei = powerlaw_graph(n, 20, seed=42, device="cuda", max_degree=int(md) if md else None)
     x = memory_features(n, seed=42, device="cuda")
     x8 = torch.nn.functional.pad(x, (0, 1)).contiguous()
     graph = default_cache().get(ei, n)
