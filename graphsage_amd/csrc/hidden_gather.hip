@@ -10,8 +10,9 @@
 //
 //   out[i,:] = inv_deg[i] * sum_{p in row i} act( [W_l1 | b1 | W_r1 | 0] . [agg1[j] | 1 | x[j] | 0] ),  j = col[p]
 //
-// One wave per chunk of 64 destination rows; their neighbours are walked in groups of 32 (four
-// slots of 8, see the group index below): the 32 rows u[j] are the A operand of
+// A wave takes chunks of 64 destination rows (drawn from a work counter: the launch is as many waves
+// as the chip holds); their neighbours are walked in groups of 32 (four slots of 8, see the group
+// index below): the 32 rows u[j] are the A operand of
 // v_mfma_f32_32x32x16_bf16 (K = 16 is exactly the layer's input width, the bias rides in the
 // padding column 7), every fp32 operand as the exact sum of three bf16 parts and the six largest
 // of the nine products issued, smallest first (project.hip, gemm_split_k: fp32-equivalent
@@ -36,6 +37,10 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 #ifndef H1_ROWS_PER_WAVE
 #define H1_ROWS_PER_WAVE 64
 #endif
+#ifndef H1_WG_WAVES_
+#define H1_WG_WAVES_ 1
+#endif
+constexpr int H1_WG_WAVES = H1_WG_WAVES_;   // waves per workgroup of the gather kernel (they share nothing)
 constexpr int H1_ROWS = H1_ROWS_PER_WAVE;   // destination rows per wave, at most 64 (one trip per wave, in-order dispatch)
 
 // ---- weight planes: Wc[n][k] = k < 7 ? W_l[n][k] : k == 7 ? b[n] : k < 15 ? W_r[n][k-8] : 0,
@@ -112,9 +117,9 @@ __global__ void __launch_bounds__(256) h1_pack_u_k(const float *__restrict__ agg
 // wave, and a 50 000-neighbour row in it keeps that wave busy for milliseconds while the rest of
 // the launch has long finished (measured at C4: 5.4 ms, against 4.5 ms on the same graph with the
 // degrees capped at 512).  A hub row is cut into PIECES of H1_PIECE neighbours (32 groups, about
-// the length of an ordinary chunk); the first H1_HUB_WAVES waves of the launch walk the piece list
-// -- dispatched first, so the long rows overlap everything else -- and leave one unscaled partial
-// row per piece, which h1_hub_combine_k adds up in piece order (fixed => reproducible) and scales.
+// the length of an ordinary chunk); the pieces are the first items the launch's waves draw from
+// their work counter -- so the long rows overlap everything else -- and each leaves one unscaled
+// partial row, which h1_hub_combine_k adds up in piece order (fixed => reproducible) and scales.
 // A piece's slot descriptors are not stored: they follow from (first position, length).
 constexpr int H1_SLOT = 8;
 constexpr int H1_META_LAST = 1 << 10, H1_META_VALID = 1 << 11;
@@ -124,12 +129,12 @@ constexpr int H1_META_LAST = 1 << 10, H1_META_VALID = 1 << 11;
 #ifndef H1_PIECE_
 #define H1_PIECE_ 1024
 #endif
-#ifndef H1_HUB_WAVES_
-#define H1_HUB_WAVES_ 8192
+#ifndef H1_GRID_WAVES_
+#define H1_GRID_WAVES_ 4096
 #endif
 constexpr int H1_HUB_T = H1_HUB_T_;
 constexpr int H1_PIECE = H1_PIECE_;              // a multiple of 32 (whole groups)
-constexpr int H1_HUB_WAVES = H1_HUB_WAVES_;      // a multiple of the 4 waves of a workgroup
+constexpr int H1_GRID_WAVES = H1_GRID_WAVES_;    // waves of the gather launch: 256 CUs x 4 SIMDs x 4 (what 128 registers allow)
 
 __device__ __forceinline__ int h1_row_slots(int deg) {
   return deg > H1_HUB_T ? 0 : deg > 0 ? (deg + H1_SLOT - 1) / H1_SLOT : 1;
@@ -228,22 +233,20 @@ static inline H1Groups h1_carve(void *buf, int64_t N, int64_t E) {
 static inline int64_t h1_piece_cap(int64_t E) { return E / H1_PIECE + E / H1_HUB_T + 1; }
 
 template <int NB, bool TRAIN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * H1_WG_WAVES)
 hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
                  const int *__restrict__ col, const float *__restrict__ inv_deg,
                  const float *__restrict__ U, const uint16_t *__restrict__ Wp, int64_t N, float scale,
                  float *__restrict__ out, int64_t out_blk, const int2 *__restrict__ pieces,
-                 const int *__restrict__ hcnt, float *__restrict__ part) {
+                 const int *__restrict__ hcnt, float *__restrict__ part, int *__restrict__ counter) {
   static_assert(!TRAIN || NB == 2, "the 64 mask bits of a row cover 64 columns");
   const int lane = gs_lane(), c = lane & 31, h = lane >> 5;
-  // the first H1_HUB_WAVES waves walk the pieces of the hub rows (a wave takes piece w, w +
-  // H1_HUB_WAVES, ... and ends when the list does), every other wave one chunk of H1_ROWS rows
-  int64_t item = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool hub = item < H1_HUB_WAVES;
-  const int n_pieces = hub ? hcnt[0] : 0;
-  if (!hub) item -= H1_HUB_WAVES;
-  if (hub ? item >= n_pieces : item * H1_ROWS >= N) return;
-
+  // The launch is as many waves as the chip holds; they draw their work from one counter: first
+  // the pieces of the hub rows (so the long rows overlap everything else), then the chunks of
+  // H1_ROWS rows in ascending order (the chip works on a compact moving window of col / out, as
+  // with in-order dispatch of one wave per chunk, but no wave slot waits for the dispatcher).
+  // Which wave computes an item has no influence on the item's result.
+  const int n_pieces = hcnt[0];
   // B operand: column 32 b + c, k = 8 h .. 8 h + 7 of the three weight planes, for the whole launch
   bf16x8 wf[NB][3];
 #pragma unroll
@@ -258,13 +261,19 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
   const int bit0 = (c & 1) * 16 + (c >> 2);
   const uint32_t u_lane = 32u * (uint32_t)h;       // byte offset of this lane's half of a 64-byte row
   const int sl = c >> 3, ln = c & 7;               // this lane's slot of a group, its place in the slot
-  // a piece's partial row is stored like row `piece` of an unblocked [pieces, 32 NB] table
-  float *const o_base = hub ? part : out;
-  const int64_t o_blk = hub ? 0 : out_blk;
 
   for (;;) {
     // ---- this wave's item: a chunk (rows row0 .. row0 + H1_ROWS, groups g0 .. g1 of the index) or a
     // piece (one run of `plen` neighbours from position pfirst of col, groups 0 .. g1)
+    int drawn = 0;
+    if (lane == 0) drawn = atomicAdd(counter, 1);
+    drawn = __builtin_amdgcn_readfirstlane(drawn);
+    const bool hub = drawn < n_pieces;
+    const int64_t item = hub ? drawn : drawn - n_pieces;
+    if (!hub && item * H1_ROWS >= N) return;
+    // a piece's partial row is stored like row `piece` of an unblocked [pieces, 32 NB] table
+    float *const o_base = hub ? part : out;
+    const int64_t o_blk = hub ? 0 : out_blk;
     const int64_t row0 = hub ? item : item * H1_ROWS;
     int g0 = 0, g1, pfirst = 0, plen = 0;
     float idg = 0.f;                                 // lane k: the scale of row k of the chunk
@@ -420,9 +429,6 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
 #undef H1_LOAD_DESC
 #undef H1_LOAD_COL
 #undef H1_LOAD_U
-    if (!hub) return;
-    item += H1_HUB_WAVES;
-    if (item >= n_pieces) return;
   }
 }
 
@@ -490,7 +496,7 @@ extern "C" size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_
   if (N < 0 || E < 0 || Fo <= 0) return 0;
   // the 64-byte rows, the weight planes, one partial row per piece of a hub row
   return gs_align_up((size_t)N * 16 * sizeof(float), 256) + gs_align_up(h1_planes_bytes(Fo), 256) +
-         gs_align_up((size_t)h1_piece_cap(E) * (size_t)Fo * sizeof(float), 256);
+         gs_align_up((size_t)h1_piece_cap(E) * (size_t)Fo * sizeof(float), 256) + 256;
 }
 
 extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *col,
@@ -515,20 +521,22 @@ extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const
   float *U = carve.take<float>((size_t)N * 16);
   uint16_t *planes = carve.take<uint16_t>((size_t)(3 * Fo * 16));
   float *part = carve.take<float>((size_t)h1_piece_cap(E) * (size_t)Fo);
+  int *counter = carve.take<int>(4);
+  if (!gs_zero_async(counter, 4 * sizeof(int), st)) return GSAGE_ERR_LAUNCH;
   hipLaunchKernelGGL(h1_pack_w_k, dim3(gs_grid(Fo * 16, 256, 16)), dim3(256), 0, st, w_l, b_l, w_r,
                      (int)Fo, planes);
   hipLaunchKernelGGL(h1_pack_u_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, agg1, x8, N,
                      train ? 1 : 0, h1, (const unsigned long long *)relu_sign, U);
   GSAGE_CHECK_LAUNCH();
-  const unsigned grid = (unsigned)((N + 4 * H1_ROWS - 1) / (4 * H1_ROWS)) + H1_HUB_WAVES / 4;
+  const unsigned grid = H1_GRID_WAVES / H1_WG_WAVES;
   const H1Groups g = h1_carve(const_cast<void *>(groups), N, E);
   const float scale = train ? 1.0f / (1.0f - p) : 1.0f;
   const int64_t blk = out_blocked ? N * 64 : 0;
 #define H1_LAUNCH(NB, TR)                                                                        \
-  hipLaunchKernelGGL((hidden1_gather_k<NB, TR>), dim3(grid), dim3(256), 0, st,                  \
+  hipLaunchKernelGGL((hidden1_gather_k<NB, TR>), dim3(grid), dim3(64 * H1_WG_WAVES), 0, st,                  \
                      (const int *)g.goff, (const int2 *)g.gdesc, col, inv_deg, (const float *)U, \
                      (const uint16_t *)planes, N, scale, out, blk, (const int2 *)g.pieces,          \
-                     (const int *)g.hcnt, part)
+                     (const int *)g.hcnt, part, counter)
   if (train) H1_LAUNCH(2, true);
   else if (Fo == 64) H1_LAUNCH(2, false);
   else if (Fo == 128) H1_LAUNCH(4, false);
