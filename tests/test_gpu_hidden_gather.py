@@ -135,6 +135,29 @@ def test_rows_around_the_hub_threshold_are_cut_into_pieces(fo, train):
     assert torch.equal(again, got)            # piece order is fixed: bitwise reproducible
 
 
+def test_graph_whose_rows_are_all_hubs():
+    """70 nodes, every one with 1 100 .. 1 300 in-edges (duplicates galore): the chunks' own lists
+    are empty, every row comes out of the pieces"""
+    from graphsage_amd import ops
+    from graphsage_amd.graph import default_cache
+    n = 70
+    g = torch.Generator().manual_seed(5)
+    parts = [torch.stack([torch.randint(0, n, (1100 + 3 * r,), generator=g), torch.full((1100 + 3 * r,), r)])
+             for r in range(n)]
+    ei = torch.cat(parts, 1)
+    x8 = torch.zeros(n, 8)
+    x8[:, :7] = torch.rand(n, 7, generator=g)
+    wl, wr = torch.zeros(128, 8), torch.zeros(128, 8)
+    wl[:, :7], wr[:, :7] = torch.randn(128, 7, generator=g) / 2, torch.randn(128, 7, generator=g) / 2
+    b = torch.randn(128, generator=g) / 4
+    graph = default_cache().get(ei.cuda(), n)
+    d = [t.cuda() for t in (x8, wl, b, wr)]
+    agg1 = ops.aggregate_mean(graph, d[0])
+    got = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU)
+    want, _ = _ref64(ei, x8, wl, b, wr, n, torch.relu)
+    assert_close(got, want, what="vs float64")
+
+
 def test_argument_checks():
     from graphsage_amd import ops
     lib = _lib.load()
