@@ -396,7 +396,7 @@ def run_training(args, R):
     # 8(d)(ii): algorithmic bytes of K2 / kernel time).  Two kernels can implement it:
     #   * the plain F=hidden segment gather over the stored activation (seg_gather_vec_k), which
     #     moves its algorithmic bytes; or
-    #   * the recompute gather (hidden1_gather_k + its two pack kernels, one bracket): it fetches the
+    #   * the recompute gather (hidden1_gather_k + its two pack kernels and the hub-row combine, one bracket): it fetches the
     #     64-byte input row of every neighbour and redoes the first layer's projection on the matrix
     #     cores, so it moves FEWER bytes than the algorithmic count.  It is priced on the same
     #     algorithmic bytes (the survey's definition: the work done, not the bytes moved), which can
@@ -419,10 +419,11 @@ def run_training(args, R):
         else (None, None, None)
     if recompute and traffic is not None:
         # the bracket also holds the kernel that writes the 64-byte rows
-        t2, _, _ = measured_traffic(args.workload, "h1_pack_u_k")
-        traffic = traffic + (t2 or 0.0)
+        for extra in ("h1_pack_u_k", "h1_hub_combine_k"):
+            t2, _, _ = measured_traffic(args.workload, extra)
+            traffic = traffic + (t2 or 0.0)
     roofline = {"bound": "hbm",
-                "kernel": (f"{rec_name} + h1_pack_u_k/h1_pack_w_k (layer-2 forward aggregation recomputed from "
+                "kernel": (f"{rec_name} + h1_pack_u_k/h1_pack_w_k/h1_hub_combine_k (layer-2 forward aggregation recomputed from "
                            f"the input layer's operands), F={F}") if recompute
                 else f"{plain_name} (hub rows included), F={F}",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
