@@ -39,6 +39,16 @@ def run(n, B, steps, captured, deterministic):
 
 if __name__ == "__main__":
     good = True
+    if len(sys.argv) > 1 and sys.argv[1] == "k2h":
+        # the recomputed layer-2 aggregation forced on at sizes where the switch would keep the plain
+        # gather: its work counter, hub-row pieces and partial rows under thousands of graph replays
+        from graphsage_amd import ops
+        ops.HIDDEN1_MIN_BYTES = 0
+        good &= run(1_000_000, 1 << 14, 3000, True, "default")
+        good &= run(1_000_000, 1 << 16, 2000, False, "default")
+        good &= run(200_000, 1 << 12, 6000, True, "default")
+        print("recomputed aggregations:", ops.HIDDEN1_STATS["used"], flush=True)
+        sys.exit(0 if good and ops.HIDDEN1_STATS["used"] > 0 else 1)
     good &= run(500, 1024, 20000, True, False)
     good &= run(500, 1024, 5000, True, True)
     good &= run(100_000, 1 << 17, 3000, False, None)
