@@ -122,10 +122,11 @@ def aggregate_mean(graph: GraphCSR, x: torch.Tensor) -> torch.Tensor:
 # those and redo the projection on the matrix cores instead of gathering the stored activation
 # (gsage_segment_gather_hidden1).  GSAGE_HIDDEN1_RECOMPUTE=0 keeps the plain gather.
 HIDDEN1_RECOMPUTE = os.environ.get("GSAGE_HIDDEN1_RECOMPUTE", "1") != "0"
-# ... from the size on where the stored activation no longer sits in the 256 MB Infinity Cache:
-# below it the plain gather reads its rows from cache and wins (measured on the benchmark graphs:
-# break-even at 1 M nodes x 64 columns in eval mode, 2 M in training, 250-300 k nodes x 128 / 256)
-HIDDEN1_MIN_BYTES = int(os.environ.get("GSAGE_HIDDEN1_MIN_BYTES", str(256 << 20)))
+# ... from the size on where it wins: below it the plain gather reads the stored activation out of
+# the caches.  Measured on the benchmark graphs (tools/hidden_gather_probe.py, pack kernels
+# included): break-even at 400 k nodes x 64 columns (eval and training alike), 150 k x 128, 100 k x
+# 256, i.e. 75 - 100 MB of activation whatever the width.
+HIDDEN1_MIN_BYTES = int(os.environ.get("GSAGE_HIDDEN1_MIN_BYTES", str(96 << 20)))
 
 
 def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int) -> bool:
@@ -137,7 +138,7 @@ def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int) -> 
     if x.size(1) != 8 or w_l.size(1) != 8 or not x.is_cuda:
         return False
     training = stash["epilogue"] == _lib.EPI_RELU_DROPOUT
-    if num_nodes * w_l.size(0) * 4 < HIDDEN1_MIN_BYTES * (2 if training else 1):
+    if num_nodes * w_l.size(0) * 4 < HIDDEN1_MIN_BYTES:
         return False
     if training and stash["sign"] is None:
         return False          # would have to read the stored activation for its zero pattern
