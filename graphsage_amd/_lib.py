@@ -36,7 +36,7 @@ SIGNATURES = {
     "gsage_segment_gather_skip": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
     "gsage_segment_gather_live": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
     "gsage_segment_gather_hidden1_supported": (C.c_int, [_i64, C.c_int]),
-    "gsage_segment_gather_hidden1_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gsage_segment_gather_hidden1_workspace_bytes": (_sz, [_i64, _i64, _i64, C.c_int]),
     "gsage_hidden1_groups_bytes": (_sz, [_i64, _i64]),
     "gsage_hidden1_groups_build": (C.c_int, [_p, _i64, _i64, _p, _sz, _p]),
     "gsage_segment_gather_hidden1": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int,

@@ -63,29 +63,32 @@ __global__ void __launch_bounds__(256) h1_pack_w_k(const float *__restrict__ wl,
 }
 
 // ---- the 64-byte rows: u[j] = [agg1[j][0..6], m_lo, x[j][0..6], m_hi].  m = the 64 keep-and-positive
-// bits of row j (Fo = 64, training), bit 16 cc + q of the 64-bit mask = column 4 q + cc: the order
+// bits of columns 0..63 of row j (training; the masks of columns 64.. follow the row, which then
+// takes 128 bytes), bit 16 cc + q of a 64-bit mask = column 4 q + cc of its group: the order
 // the first-layer kernel's ballots come in (gsage_relu_sign_bytes: per 4 rows and column block four
 // 64-bit words, word cc bit l = column 4 (l & 15) + cc of row l >> 4), so a row's mask is the four
 // 16-bit fields of its group's words.  No sign bits (other forward kernels): taken from h1 > 0.
 __global__ void __launch_bounds__(256) h1_pack_u_k(const float *__restrict__ agg1, const float *__restrict__ x8,
-                                                   int64_t N, int train, const float *__restrict__ h1,
+                                                   int64_t N, int train, int ngroups, const float *__restrict__ h1,
                                                    const unsigned long long *__restrict__ sign,
                                                    float *__restrict__ U) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   // the flag word behind the bits says whether the forward kernel that ran wrote them
-  const bool have_bits = train && sign && sign[((N + 3) >> 2) * 4] != 0ull;
+  const int64_t ngrp4 = (N + 3) >> 2;
+  const bool have_bits = train && sign && sign[ngrp4 * 4 * ngroups] != 0ull;
   if (j >= N) return;
   f32x4v a0 = *(const f32x4v *)(agg1 + j * 8), a1 = *(const f32x4v *)(agg1 + j * 8 + 4);
   f32x4v b0 = *(const f32x4v *)(x8 + j * 8), b1 = *(const f32x4v *)(x8 + j * 8 + 4);
-  uint32_t lo = 0u, hi = 0u;
-  if (train) {
+  // the mask of columns 64 g .. 64 g + 63 (group g), as two words
+  auto mask_of = [&](int g, uint32_t &lo, uint32_t &hi) {
+    lo = 0u; hi = 0u;
     if (have_bits) {
-      const unsigned long long *w = sign + (j >> 2) * 4;
+      const unsigned long long *w = sign + ((int64_t)g * ngrp4 + (j >> 2)) * 4;
       const int sh = 16 * (int)(j & 3);
       lo = (uint32_t)((w[0] >> sh) & 0xFFFFull) | ((uint32_t)((w[1] >> sh) & 0xFFFFull) << 16);
       hi = (uint32_t)((w[2] >> sh) & 0xFFFFull) | ((uint32_t)((w[3] >> sh) & 0xFFFFull) << 16);
     } else {
-      const float *r = h1 + j * 64;
+      const float *r = h1 + j * (64 * ngroups) + 64 * g;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const f32x4v v = *(const f32x4v *)(r + 4 * q);
@@ -93,14 +96,29 @@ __global__ void __launch_bounds__(256) h1_pack_u_k(const float *__restrict__ agg
         hi |= (v[2] > 0.f ? 1u : 0u) << q | (v[3] > 0.f ? 1u : 0u) << (16 + q);
       }
     }
-  }
+  };
+  uint32_t lo = 0u, hi = 0u;
+  if (train) mask_of(0, lo, hi);
   a1[3] = __uint_as_float(lo);
   b1[3] = __uint_as_float(hi);
-  float *u = U + j * 16;
+  // rows of 64 bytes; training on more than 64 columns: 128 bytes (still one line per neighbour),
+  // the masks of the further column groups behind the row, low words at byte 64, high words at 80
+  float *u = U + j * (train && ngroups > 1 ? 32 : 16);
   *(f32x4v *)(u) = a0;
   *(f32x4v *)(u + 4) = a1;
   *(f32x4v *)(u + 8) = b0;
   *(f32x4v *)(u + 12) = b1;
+  if (train && ngroups > 1) {
+    u32x4v xl = {0u, 0u, 0u, 0u}, xh = {0u, 0u, 0u, 0u};
+    for (int g = 1; g < ngroups; ++g) {
+      uint32_t l, h_;
+      mask_of(g, l, h_);
+      xl[g - 1] = l;
+      xh[g - 1] = h_;
+    }
+    *(u32x4v *)(u + 16) = xl;
+    *(u32x4v *)(u + 20) = xh;
+  }
 }
 
 // ---- group index, cut once per graph.  The matrix instruction takes 32 neighbours at a time, a
@@ -239,7 +257,9 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
                  const float *__restrict__ U, const uint16_t *__restrict__ Wp, int64_t N, float scale,
                  float *__restrict__ out, int64_t out_blk, const int2 *__restrict__ pieces,
                  const int *__restrict__ hcnt, float *__restrict__ part, int *__restrict__ counter) {
-  static_assert(!TRAIN || NB == 2, "the 64 mask bits of a row cover 64 columns");
+  // bytes per row of the table: training on more than 64 columns carries the further column
+  // groups' masks behind the 64-byte row (h1_pack_u_k)
+  constexpr uint32_t UROW = (TRAIN && NB > 2) ? 128u : 64u;
   const int lane = gs_lane(), c = lane & 31, h = lane >> 5;
   // The launch is as many waves as the chip holds; they draw their work from one counter: first
   // the pieces of the hub rows (so the long rows overlap everything else), then the chunks of
@@ -311,19 +331,22 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
     DST = -1;                                                                                 \
     if (ln < ((DESC).y & 15)) DST = col[(DESC).x + ln];                                       \
   }
-#define H1_LOAD_U(A, B, ID)                                                                   \
+#define H1_LOAD_U(A, B, X, ID)                                                                \
   {                                                                                           \
     A = (f32x4v){0.f, 0.f, 0.f, 0.f};                                                         \
     B = (f32x4v){0.f, 0.f, 0.f, 0.f};                                                         \
+    X = (u32x4v){0u, 0u, 0u, 0u};                                                             \
     if ((ID) >= 0) {                                                                          \
-      const char *p_ = (const char *)U + ((uint32_t)(ID) * 64u + u_lane);                     \
+      const char *p_ = (const char *)U + ((uint32_t)(ID) * UROW + u_lane);                    \
       A = *(const f32x4v *)p_;                                                                \
       B = *(const f32x4v *)(p_ + 16);                                                         \
+      if (UROW > 64u) X = *(const u32x4v *)(p_ + (64 - 16 * h));   /* byte 64 + 16 h of the row */ \
     }                                                                                         \
   }
     int2 d0, d1, d2, d3;          // descriptors of group g, g + 1, g + 2, g + 3 (this lane's slot)
     int id1, id2;                 // neighbour ids of g + 1, g + 2
     f32x4v ua, ub;                // the row of g
+    u32x4v ux;                    // (wide training) the masks of its column groups 1, 2, 3
     bool live;
     {
       int id0;
@@ -332,17 +355,24 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
       H1_LOAD_DESC(d2, g0 + 2)
       H1_LOAD_COL(id0, d0)
       H1_LOAD_COL(id1, d1)
-      H1_LOAD_U(ua, ub, id0)
+      H1_LOAD_U(ua, ub, ux, id0)
       live = id0 >= 0;
     }
     for (int g = g0; g < g1; ++g) {
       f32x4v na, nb;
-      H1_LOAD_U(na, nb, id1)
+      u32x4v nx;
+      H1_LOAD_U(na, nb, nx, id1)
       H1_LOAD_COL(id2, d2)
       H1_LOAD_DESC(d3, g + 3)
       // ---- this group: A operand = row of neighbour c, k = 8 h .. 8 h + 7
-      uint32_t mword = 0u;
-      if (TRAIN) mword = live ? __float_as_uint(ub[3]) : 0u;
+      uint32_t mword[NB / 2];
+#pragma unroll
+      for (int g_ = 0; g_ < NB / 2; ++g_) mword[g_] = 0u;
+      if (TRAIN) {
+        mword[0] = live ? __float_as_uint(ub[3]) : 0u;
+#pragma unroll
+        for (int g_ = 1; g_ < NB / 2; ++g_) mword[g_] = ux[g_ - 1];     // zero without a neighbour
+      }
       ub[3] = (live && h == 0) ? 1.f : 0.f;          // k = 7: the bias column; k = 15: nothing
       uint32_t p1[8], p2[8], p3[8];
 #pragma unroll
@@ -385,8 +415,8 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int nb_ = (r & 3) + 8 * (r >> 2);
-              const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 4 * nb_, (int)mword);
-              const int keep = __builtin_amdgcn_sbfe((int)m, bit0 + 8 * b, 1);     // 0 or -1
+              const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_base + 4 * nb_, (int)mword[bp]);
+              const int keep = __builtin_amdgcn_sbfe((int)m, bit0 + 8 * bb, 1);    // 0 or -1
               v[r] = __uint_as_float((uint32_t)keep & __float_as_uint(acc[r]));
             }
           } else {
@@ -425,6 +455,7 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
       id1 = id2;
       ua = na;
       ub = nb;
+      ux = nx;
     }
 #undef H1_LOAD_DESC
 #undef H1_LOAD_COL
@@ -488,14 +519,19 @@ extern "C" int gsage_hidden1_groups_build(const int32_t *rowptr, int64_t N, int6
 
 extern "C" int gsage_segment_gather_hidden1_supported(int64_t Fo, int epilogue) {
   if (epilogue == GSAGE_EPI_RELU) return (Fo == 64 || Fo == 128 || Fo == 256) ? 1 : 0;
-  if (epilogue == GSAGE_EPI_RELU_DROPOUT) return Fo == 64 ? 1 : 0;
+  if (epilogue == GSAGE_EPI_RELU_DROPOUT) return (Fo == 64 || Fo == 128 || Fo == 256) ? 1 : 0;
   return 0;
 }
 
-extern "C" size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t E, int64_t Fo) {
+// bytes per row of the table u[j]: 64, or 128 when the masks of more than 64 columns ride along
+static inline size_t h1_urow_bytes(int64_t Fo, int epilogue) {
+  return epilogue == GSAGE_EPI_RELU_DROPOUT && Fo > 64 ? 128 : 64;
+}
+
+extern "C" size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t E, int64_t Fo, int epilogue) {
   if (N < 0 || E < 0 || Fo <= 0) return 0;
-  // the 64-byte rows, the weight planes, one partial row per piece of a hub row
-  return gs_align_up((size_t)N * 16 * sizeof(float), 256) + gs_align_up(h1_planes_bytes(Fo), 256) +
+  // the rows u[j], the weight planes, one partial row per piece of a hub row, the work counter
+  return gs_align_up((size_t)N * h1_urow_bytes(Fo, epilogue), 256) + gs_align_up(h1_planes_bytes(Fo), 256) +
          gs_align_up((size_t)h1_piece_cap(E) * (size_t)Fo * sizeof(float), 256) + 256;
 }
 
@@ -514,11 +550,13 @@ extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const
   if (train && (!(p >= 0.f && p < 1.f) || (!h1 && !relu_sign))) return GSAGE_ERR_INVALID_ARG;
   if (out_blocked && Fo % 64 != 0) return GSAGE_ERR_UNSUPPORTED;
   if ((((uintptr_t)agg1 | (uintptr_t)x8 | (uintptr_t)h1 | (uintptr_t)ws) & 15) != 0) return GSAGE_ERR_UNSUPPORTED;
-  if (ws_bytes < gsage_segment_gather_hidden1_workspace_bytes(N, E, Fo)) return GSAGE_ERR_WORKSPACE;
+  if (ws_bytes < gsage_segment_gather_hidden1_workspace_bytes(N, E, Fo, epilogue)) return GSAGE_ERR_WORKSPACE;
+  // 32-bit byte offsets into the row table
+  if ((uint64_t)N * h1_urow_bytes(Fo, epilogue) > ((uint64_t)1 << 32)) return GSAGE_ERR_UNSUPPORTED;
   if (N == 0) return GSAGE_OK;     // (col may be NULL: a graph without edges has nothing to index)
   hipStream_t st = gs_stream(stream);
   GsCarver carve(ws);
-  float *U = carve.take<float>((size_t)N * 16);
+  float *U = carve.take<float>((size_t)N * (h1_urow_bytes(Fo, epilogue) / 4));
   uint16_t *planes = carve.take<uint16_t>((size_t)(3 * Fo * 16));
   float *part = carve.take<float>((size_t)h1_piece_cap(E) * (size_t)Fo);
   int *counter = carve.take<int>(4);
@@ -526,7 +564,7 @@ extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const
   hipLaunchKernelGGL(h1_pack_w_k, dim3(gs_grid(Fo * 16, 256, 16)), dim3(256), 0, st, w_l, b_l, w_r,
                      (int)Fo, planes);
   hipLaunchKernelGGL(h1_pack_u_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, agg1, x8, N,
-                     train ? 1 : 0, h1, (const unsigned long long *)relu_sign, U);
+                     train ? 1 : 0, (int)(Fo / 64), h1, (const unsigned long long *)relu_sign, U);
   GSAGE_CHECK_LAUNCH();
   const unsigned grid = H1_GRID_WAVES / H1_WG_WAVES;
   const H1Groups g = h1_carve(const_cast<void *>(groups), N, E);
@@ -537,7 +575,9 @@ extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const
                      (const int *)g.goff, (const int2 *)g.gdesc, col, inv_deg, (const float *)U, \
                      (const uint16_t *)planes, N, scale, out, blk, (const int2 *)g.pieces,          \
                      (const int *)g.hcnt, part, counter)
-  if (train) H1_LAUNCH(2, true);
+  if (train && Fo == 64) H1_LAUNCH(2, true);
+  else if (train && Fo == 128) H1_LAUNCH(4, true);
+  else if (train) H1_LAUNCH(8, true);
   else if (Fo == 64) H1_LAUNCH(2, false);
   else if (Fo == 128) H1_LAUNCH(4, false);
   else H1_LAUNCH(8, false);

@@ -171,7 +171,7 @@ def aggregate_hidden1(graph: GraphCSR, agg1, x8, w_l, b_l, w_r, epilogue, p: flo
             raise ValueError(f"{name} must be contiguous float32 with 8 columns (7 features padded)")
     with torch.cuda.device(dev):
         out = torch.empty((Fo // 64, N, 64) if out_blocked else (N, Fo), dtype=torch.float32, device=dev)
-        ws_bytes = lib.gsage_segment_gather_hidden1_workspace_bytes(N, graph.num_edges, Fo)
+        ws_bytes = lib.gsage_segment_gather_hidden1_workspace_bytes(N, graph.num_edges, Fo, int(epilogue))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         ev = _timer.bracket(f"segment_gather_hidden1_F{Fo}") if _timer is not None and _timer.enabled else None
         if ev:

@@ -139,14 +139,15 @@ int gsage_segment_gather_ew(const int32_t *rowptr, const int32_t *col, const flo
  *   out[i,:] = inv_deg[i] * sum_{p in row i} act(W_l1 . agg1[col[p]] + b1 + W_r1 . x8[col[p]])
  *   agg1, x8 : fp32 [N,8], column 7 of both ZERO (the 7 input features padded to 8; the bias
  *              rides in that column), w_l / w_r : fp32 [Fo,8] padded alike, b_l [Fo]
- *   epilogue : GSAGE_EPI_RELU (Fo = 64, 128, 256) or GSAGE_EPI_RELU_DROPOUT (Fo = 64: the 64
- *              keep-and-positive bits of a row travel in its two padding columns).  Training takes
- *              the zero pattern of the h1 that was STORED, so both agree on which elements exist:
+ *   epilogue : GSAGE_EPI_RELU or GSAGE_EPI_RELU_DROPOUT, Fo = 64, 128 or 256.  Training takes the
+ *              zero pattern of the h1 that was STORED, so both agree on which elements exist: a
+ *              row's keep-and-positive bits travel with its 64-byte row (64 columns: in its two
+ *              padding columns; more: behind it, the row then takes 128 bytes of the same line).
  *              relu_sign = the bits gsage_project_fwd_ex left (used if its flag word says they
- *              were written), else h1 [N,64] is read for h1 > 0; one of the two must be given.
+ *              were written), else h1 [N,Fo] is read for h1 > 0; one of the two must be given.
  *              Values are recomputed, i.e. equal to the stored ones up to fp32 rounding.
  *   out      : fp32 [N,Fo] row-major, or column-blocked (out_blocked, gsage_project_fwd_blocked)
- *   ws       : gsage_segment_gather_hidden1_workspace_bytes(N, E, Fo) bytes (the 64-byte rows, the
+ *   ws       : gsage_segment_gather_hidden1_workspace_bytes(N, E, Fo, epilogue) bytes (the rows, the
  *              weight planes, one partial row per 1 024 neighbours of a hub row).
  *   groups   : the graph's group index, built ONCE per CSR by gsage_hidden1_groups_build into
  *              gsage_hidden1_groups_bytes(N, E) bytes: every row's neighbours cut into groups of
@@ -158,7 +159,7 @@ size_t gsage_hidden1_groups_bytes(int64_t N, int64_t E);
 int gsage_hidden1_groups_build(const int32_t *rowptr, int64_t N, int64_t E, void *groups,
                                size_t groups_bytes, gsage_stream_t stream);
 int gsage_segment_gather_hidden1_supported(int64_t Fo, int epilogue);
-size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t E, int64_t Fo);
+size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t E, int64_t Fo, int epilogue);
 int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *col,
                                  const float *inv_deg, const float *agg1, const float *x8, const float *w_l,
                                  const float *b_l, const float *w_r, int64_t N, int64_t Fo,

@@ -112,12 +112,14 @@ def test_recompute_gather_and_range_entry_points_validate_before_touching_the_de
     # which shapes the recomputed aggregation takes
     sup = lib.gsage_segment_gather_hidden1_supported
     assert sup(64, _lib.EPI_RELU) == 1 and sup(128, _lib.EPI_RELU) == 1 and sup(256, _lib.EPI_RELU) == 1
-    assert sup(64, _lib.EPI_RELU_DROPOUT) == 1 and sup(128, _lib.EPI_RELU_DROPOUT) == 0   # 64 mask bits per row
+    assert sup(64, _lib.EPI_RELU_DROPOUT) == 1 and sup(128, _lib.EPI_RELU_DROPOUT) == 1 and sup(96, _lib.EPI_RELU_DROPOUT) == 0
     assert sup(96, _lib.EPI_RELU) == 0 and sup(64, _lib.EPI_NONE) == 0 and sup(64, _lib.EPI_L2NORM) == 0
     # sizes: the 64-byte rows + weight planes; the group index (<= N + E/8 slots of 8 bytes + offsets)
     n, e = 10_000_000, 200_000_000
-    assert n * 64 <= lib.gsage_segment_gather_hidden1_workspace_bytes(n, e, 64) <= n * 64 * 1.2
-    assert lib.gsage_segment_gather_hidden1_workspace_bytes(-1, e, 64) == 0
+    assert n * 64 <= lib.gsage_segment_gather_hidden1_workspace_bytes(n, e, 64, _lib.EPI_RELU_DROPOUT) <= n * 64 * 1.2
+    assert lib.gsage_segment_gather_hidden1_workspace_bytes(-1, e, 64, _lib.EPI_RELU) == 0
+    # training on more than 64 columns: 128-byte rows (the masks of the further column groups ride along)
+    assert lib.gsage_segment_gather_hidden1_workspace_bytes(n, e, 128, _lib.EPI_RELU_DROPOUT) >= n * 128
     g = lib.gsage_hidden1_groups_bytes(n, e)
     assert (n + e // 8) * 8 <= g <= 2 * (n + e // 8) * 8 + e // 64
     assert lib.gsage_hidden1_groups_bytes(-1, 0) == 0

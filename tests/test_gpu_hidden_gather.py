@@ -59,12 +59,14 @@ def test_eval_matches_the_gather_over_the_stored_activation(n, deg, fo):
 
 @pytest.mark.parametrize("n,deg", [(1, 1), (333, 5), (5000, 20), (20000, 40)])
 @pytest.mark.parametrize("bits", ["sign", "h1"])
-def test_training_takes_the_zero_pattern_of_the_stored_activation(n, deg, bits):
+@pytest.mark.parametrize("fo", [64, 128, 256])
+def test_training_takes_the_zero_pattern_of_the_stored_activation(n, deg, bits, fo):
+    """(more than 64 columns: the masks of the further column groups ride behind the 64-byte row)"""
     from graphsage_amd import ops
     p = 0.3
-    ei, x8, wl, b, wr, graph = _setup(n, 64, deg, seed=7 * n)
+    ei, x8, wl, b, wr, graph = _setup(n, fo, deg, seed=7 * n + fo)
     d = [t.cuda() for t in (x8, wl, b, wr)]
-    keep = (torch.rand(n, 64, generator=torch.Generator().manual_seed(n)) >= p).to(torch.uint8)
+    keep = (torch.rand(n, fo, generator=torch.Generator().manual_seed(n)) >= p).to(torch.uint8)
     agg1 = ops.aggregate_mean(graph, d[0])
     h1, _, sign = ops.project_fwd(agg1, d[0], d[1], d[2], d[3], epilogue=_lib.EPI_RELU_DROPOUT,
                                   keep_mask=keep.cuda(), p=p, want_relu_sign=True)
@@ -99,7 +101,7 @@ def test_isolated_rows_hub_rows_and_duplicate_edges():
     assert torch.count_nonzero(got[1:5000]).item() == 0       # leaves of the star have no in-edges
 
 
-@pytest.mark.parametrize("fo,train", [(64, False), (64, True), (256, False)])
+@pytest.mark.parametrize("fo,train", [(64, False), (64, True), (256, False), (128, True)])
 def test_rows_around_the_hub_threshold_are_cut_into_pieces(fo, train):
     """rows of 1 023 .. 3 000 neighbours among ordinary ones: above 1 024 a row is summed in pieces
     of 1 024 by other waves and put together afterwards (1 025 = a full piece and one neighbour)"""
@@ -162,7 +164,8 @@ def test_argument_checks():
     from graphsage_amd import ops
     lib = _lib.load()
     assert lib.gsage_segment_gather_hidden1_supported(64, _lib.EPI_RELU_DROPOUT) == 1
-    assert lib.gsage_segment_gather_hidden1_supported(128, _lib.EPI_RELU_DROPOUT) == 0
+    assert lib.gsage_segment_gather_hidden1_supported(128, _lib.EPI_RELU_DROPOUT) == 1
+    assert lib.gsage_segment_gather_hidden1_supported(96, _lib.EPI_RELU_DROPOUT) == 0
     assert lib.gsage_segment_gather_hidden1_supported(256, _lib.EPI_RELU) == 1
     assert lib.gsage_segment_gather_hidden1_supported(96, _lib.EPI_RELU) == 0
     assert lib.gsage_segment_gather_hidden1_supported(64, _lib.EPI_L2NORM) == 0
@@ -175,7 +178,8 @@ def test_argument_checks():
         ops.aggregate_hidden1(graph, agg1[:, :7].contiguous(), d[0], d[1], d[2], d[3], _lib.EPI_RELU)
 
 
-@pytest.mark.parametrize("hidden,layers,train", [(64, 2, True), (64, 2, False), (64, 3, True), (256, 3, False)])
+@pytest.mark.parametrize("hidden,layers,train", [(64, 2, True), (64, 2, False), (64, 3, True), (256, 3, False),
+                                                 (128, 2, True), (256, 3, True)])
 def test_model_with_the_recomputed_aggregation_equals_the_plain_path(monkeypatch, hidden, layers, train):
     """GraphSAGE.forward with the second layer's aggregation recomputed (forced on: small graphs
     keep the plain gather by default) against the same model on the plain path: embeddings, and
