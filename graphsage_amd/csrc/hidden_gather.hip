@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) h1_pack_u_k(const float *__restrict__ agg
       const int sh = 16 * (int)(j & 3);
       lo = (uint32_t)((w[0] >> sh) & 0xFFFFull) | ((uint32_t)((w[1] >> sh) & 0xFFFFull) << 16);
       hi = (uint32_t)((w[2] >> sh) & 0xFFFFull) | ((uint32_t)((w[3] >> sh) & 0xFFFFull) << 16);
-    } else {
+    } else if (h1) {      // (neither source: the mask stays empty and the row contributes nothing)
       const float *r = h1 + j * (64 * ngroups) + 64 * g;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {

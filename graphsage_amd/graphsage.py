@@ -37,6 +37,18 @@ def vector_width(f: int) -> int:
     return f
 
 
+_M64 = (1 << 64) - 1
+
+
+def mix_seed(base: int, step: int, layer: int = 0) -> int:
+    """64-bit seed for (base seed, step number, layer): splitmix64 of their combination, pure
+    integer arithmetic on the host (no generator state involved)."""
+    z = (int(base) + 0x9E3779B97F4A7C15 * (int(step) * 64 + int(layer) + 1)) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return (z ^ (z >> 31)) & _M64
+
+
 class SAGEConv(nn.Module):
     """Mean-aggregating SAGEConv: ``lin_l(mean_{j->i} x_j) + lin_r(x_i)``.
 
@@ -120,8 +132,21 @@ class GraphSAGE(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self._force_generic = False
         self.convs[0].cache_aggregation = bool(cache_input_aggregation)
+        # (base seed, step number) set by an owner that counts steps itself (TrainStep): the
+        # in-kernel dropout hash is then seeded from those two numbers and the layer index alone,
+        # so replicas that were given the same base seed draw the same masks whatever else their
+        # processes did with torch's generators.  None: one draw from the CPU generator per layer.
+        self._dropout_stream: Optional[tuple] = None
 
-    def _dropout_seed(self) -> int:
+    def set_dropout_stream(self, base_seed: Optional[int], step: int = 0) -> None:
+        """Seed the dropout masks of the next training-mode forward from ``(base_seed, step,
+        layer)`` instead of torch's CPU generator; ``None`` goes back to the generator."""
+        self._dropout_stream = None if base_seed is None else (int(base_seed), int(step))
+
+    def _dropout_seed(self, layer: int = 0) -> int:
+        if self._dropout_stream is not None:
+            base, step = self._dropout_stream
+            return mix_seed(base, step, layer)
         # CPU generator: reproducible under torch.manual_seed, no device sync
         return int(torch.empty((), dtype=torch.int64).random_().item())
 
@@ -149,7 +174,7 @@ class GraphSAGE(nn.Module):
         for i, conv in enumerate(self.convs[:-1]):
             if training:
                 km = keep_masks[i] if keep_masks is not None else None
-                seed = 0 if km is not None else self._dropout_seed()
+                seed = 0 if km is not None else self._dropout_seed(i)
                 x = conv.run(x, graph, _lib.EPI_RELU_DROPOUT, p, seed, km, self._force_generic,
                              input_layer=i == 0, agg=agg_for(i), stash=stash if i == 0 else None)
             else:

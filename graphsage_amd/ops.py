@@ -140,8 +140,12 @@ def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int) -> 
     training = stash["epilogue"] == _lib.EPI_RELU_DROPOUT
     if num_nodes * w_l.size(0) * 4 < HIDDEN1_MIN_BYTES:
         return False
-    if training and stash["sign"] is None:
-        return False          # would have to read the stored activation for its zero pattern
+    # the kernel addresses its row table with 32-bit byte offsets: 64-byte rows, or 128-byte rows
+    # when the dropout masks of more than 64 columns ride behind them
+    if num_nodes * (128 if training and w_l.size(0) > 64 else 64) > (1 << 32):
+        return False
+    if training and stash["sign"] is None and stash.get("out") is None:
+        return False          # nothing to take the stored activation's zero pattern from
     return bool(_lib.load().gsage_segment_gather_hidden1_supported(w_l.size(0), int(stash["epilogue"])))
 
 
@@ -154,7 +158,10 @@ def aggregate_hidden1_from(graph: GraphCSR, stash: dict, out_blocked: bool = Fal
         return aggregate_hidden1(graph, stash["agg"], stash["x"], stash["w_l"].detach().contiguous(),
                                  stash["b_l"].detach(), stash["w_r"].detach().contiguous(),
                                  stash["epilogue"], p=stash["p"], relu_sign=stash["sign"],
-                                 out_blocked=out_blocked)
+                                 # training: the stored activation too, which the kernel reads for
+                                 # the zero pattern when the forward kernel that ran left no sign
+                                 # bits (unaligned operands or mask: the flag word behind the bits)
+                                 h1=stash.get("out"), out_blocked=out_blocked)
 
 
 def aggregate_hidden1(graph: GraphCSR, agg1, x8, w_l, b_l, w_r, epilogue, p: float = 0.0,
@@ -549,7 +556,8 @@ class SAGELayerFunction(torch.autograd.Function):
         ctx.save_for_backward(x, agg, out, rnorm, w_l, w_r, sign)
         if stash is not None:
             # what the next layer's aggregation can be recomputed from (aggregate_hidden1)
-            stash.update(agg=agg, x=x, w_l=w_l, b_l=b_l, w_r=w_r, sign=sign, epilogue=epilogue, p=p)
+            stash.update(agg=agg, x=x, w_l=w_l, b_l=b_l, w_r=w_r, sign=sign, epilogue=epilogue, p=p,
+                         out=out if epilogue == _lib.EPI_RELU_DROPOUT else None)
         return out
 
     @staticmethod

@@ -5,8 +5,13 @@ import numpy as np
 
 def dropout_keep_mask(seed: int, n_rows: int, n_cols: int, p: float) -> np.ndarray:
     """uint8 [n_rows, n_cols]; 1 where the kernel keeps element (row, col)."""
+    return dropout_keep_mask_range(seed, 0, n_rows * n_cols, p).reshape(n_rows, n_cols)
+
+
+def dropout_keep_mask_range(seed: int, first: int, count: int, p: float) -> np.ndarray:
+    """uint8 [count]: elements first .. first + count of the row-major [N, F] activation."""
     seed &= 0xFFFFFFFFFFFFFFFF
-    idx = np.arange(n_rows * n_cols, dtype=np.uint64)
+    idx = np.arange(count, dtype=np.uint64) + np.uint64(first)
     lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     hi = (idx >> np.uint64(32)).astype(np.uint32)
     with np.errstate(over="ignore"):
@@ -18,7 +23,7 @@ def dropout_keep_mask(seed: int, n_rows: int, n_cols: int, p: float) -> np.ndarr
         h = h * np.uint32(0xC2B2AE35)
         h = h ^ (h >> np.uint32(16))
     u = (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    return (u >= np.float32(p)).astype(np.uint8).reshape(n_rows, n_cols)
+    return (u >= np.float32(p)).astype(np.uint8)
 
 
 def _fmix32(h: np.ndarray) -> np.ndarray:

@@ -85,6 +85,15 @@ class DegreeBiasedNegativeSampler:
         """Restart the device draw stream at counter 0 of ``seed`` (tests, reproducible runs)."""
         self._seed, self._draws = int(seed), 0
 
+    def state_dict(self) -> dict:
+        """Seed and position of the device draw stream (checkpoints: a resumed run continues the
+        stream instead of starting another)."""
+        return {"seed": self._seed, "draws": int(self._draws)}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self._seed = None if sd.get("seed") is None else int(sd["seed"])
+        self._draws = int(sd.get("draws", 0))
+
     def get_probability(self, node_idx: int) -> float:
         return self.probs[node_idx].item()
 

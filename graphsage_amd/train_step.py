@@ -60,7 +60,14 @@ class TrainStep:
                  learning_rate: float = 1e-3, weight_decay: float = 0.0,
                  gradient_clip: float = 1.0, scale_factor: float = 5.0,
                  process_group: Optional[dist.ProcessGroup] = None,
-                 loss_fn: Optional[nn.Module] = None, receptive_field: bool = False):
+                 loss_fn: Optional[nn.Module] = None, receptive_field: bool = False,
+                 seed: Optional[int] = None, distributed: Optional[bool] = None):
+        """``distributed=False``: ignore an initialised process group (a single-process stepper
+        next to a sharded one, as the parity checks build).  ``seed``: base seed of the step's device-side random streams (the dropout masks; the
+        trainer derives its negative sampler's from it too).  None draws one from torch's CPU
+        generator (so ``torch.manual_seed`` reproduces a run).  With a process group the value of
+        rank 0 is broadcast once, here: replicas then draw identical masks for step s whatever
+        else each process does with its generators afterwards."""
         self.model = model
         self.features = features
         self.edge_index = edge_index
@@ -83,10 +90,39 @@ class TrainStep:
         self._captured_versions = None
         # opt-in (graphsage_amd/receptive.py): compute only the 2-hop closure of the batch
         self.receptive_field = bool(receptive_field)
-        self.distributed = dist.is_available() and dist.is_initialized()
+        self.distributed = dist.is_available() and dist.is_initialized() and distributed is not False
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self.rank = dist.get_rank(process_group) if self.distributed else 0
+        if seed is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        self.base_seed = self._agree_on_seed(int(seed))
+        self.steps_done = 0              # index of the next step in the dropout stream
+
+    def _agree_on_seed(self, seed: int) -> int:
+        """Rank 0's base seed for everybody (one 8-byte broadcast at construction)."""
+        if self.world <= 1:
+            return seed
+        on_host = dist.get_backend(self.group) == "gloo"
+        dev = torch.device("cpu") if on_host or not self.features.is_cuda else self.features.device
+        t = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                       group=self.group)
+        return int(t.item())
+
+    def _arm_dropout(self) -> None:
+        """Masks of this step = f(base seed, step number, layer): no generator state involved."""
+        arm = getattr(self.model, "set_dropout_stream", None)
+        if arm is not None:
+            arm(self.base_seed, self.steps_done)
+        self.steps_done += 1
+
+    def state_dict(self) -> Dict[str, int]:
+        """What a resumed run needs to continue the same random streams."""
+        return {"base_seed": self.base_seed, "steps_done": self.steps_done}
+
+    def load_state_dict(self, sd: Dict[str, int]) -> None:
+        self.base_seed, self.steps_done = int(sd["base_seed"]), int(sd["steps_done"])
 
     def step(self, targets: torch.Tensor, contexts: torch.Tensor, negatives: torch.Tensor,
              global_batch: Optional[int] = None) -> torch.Tensor:
@@ -96,6 +132,7 @@ class TrainStep:
         if global_batch is None:
             global_batch = targets.numel() * self.world
         self.model.train()
+        self._arm_dropout()
         self.flat.zero_grad()
         if self.receptive_field:
             from .graph import default_cache

@@ -178,6 +178,15 @@ class GraphSAGETrainer:
             self.stepper.world == 1 and len(self.batch_generator) > 1 and \
             self.train_pairs[0].numel() >= self.batch_size and not self.stepper.receptive_field
         self._graph_ready = False
+        # the reference builds its stopping rule once (trainer.py:166): patience counter and best
+        # value carry over when train() is called again
+        self.early_stopping = EarlyStopping(self.patience, self.min_delta)
+        # the sampler's device draw stream hangs on the stepper's base seed (which rank 0 chose
+        # for everybody), one independent stream per rank: each rank draws its own shard's
+        # negatives, and no rank's stream depends on what its CPU generator was used for
+        if hasattr(negative_sampler, "reseed") and getattr(negative_sampler, "_seed", None) is None:
+            from .graphsage import mix_seed
+            negative_sampler.reseed(mix_seed(self.stepper.base_seed, 0x5EED, self.stepper.rank))
         self.optimizer = self.stepper.optimizer
         self.loss_fn = self.stepper.loss_fn
         self.best_loss = float("inf")
@@ -224,7 +233,6 @@ class GraphSAGETrainer:
 
     def train(self, num_epochs: int) -> float:
         """``trainer.py:299-364``: epochs with validation, best-model checkpoint, early stop."""
-        self.early_stopping = EarlyStopping(self.patience, self.min_delta)
         for epoch in range(num_epochs):
             self.current_epoch = epoch
             t0 = time.time()
@@ -260,7 +268,11 @@ class GraphSAGETrainer:
         state = {"epoch": self.current_epoch, "model_state_dict": self.model.state_dict(),
                  "optimizer_state_dict": self.stepper.optimizer_state_dict(),
                  "best_loss": self.best_loss, "best_value": self.best_loss,
-                 "best_epoch": self.best_epoch, "config": self.config}
+                 "best_epoch": self.best_epoch, "config": self.config,
+                 # not in the reference: where the device-side random streams stand
+                 "random_streams": {"stepper": self.stepper.state_dict(),
+                                    "sampler": self.batch_generator.negative_sampler.state_dict()
+                                    if hasattr(self.batch_generator.negative_sampler, "state_dict") else None}}
         state.update(extra)
         torch.save(state, path)
 
@@ -271,6 +283,12 @@ class GraphSAGETrainer:
         self._graph_ready = False        # the optimiser state tensors may be new objects: recapture
         self.current_epoch = ckpt.get("epoch", 0)
         self.best_loss = ckpt.get("best_loss", float("inf"))
+        streams = ckpt.get("random_streams")
+        if streams:
+            self.stepper.load_state_dict(streams["stepper"])
+            sampler = self.batch_generator.negative_sampler
+            if streams.get("sampler") is not None and hasattr(sampler, "load_state_dict"):
+                sampler.load_state_dict(streams["sampler"])
 
 
 class StreamingBatchGenerator:

@@ -145,6 +145,10 @@ int gsage_segment_gather_ew(const int32_t *rowptr, const int32_t *col, const flo
  *              padding columns; more: behind it, the row then takes 128 bytes of the same line).
  *              relu_sign = the bits gsage_project_fwd_ex left (used if its flag word says they
  *              were written), else h1 [N,Fo] is read for h1 > 0; one of the two must be given.
+ *              Give BOTH unless the caller knows which forward kernel ran: with relu_sign alone
+ *              and a flag word that says "not written" (unaligned operands or keep mask sent the
+ *              forward to a kernel that leaves no bits) there is no zero pattern to take, every
+ *              mask comes out empty and out is all zero (no fault; graphsage_amd always passes h1).
  *              Values are recomputed, i.e. equal to the stored ones up to fp32 rounding.
  *   out      : fp32 [N,Fo] row-major, or column-blocked (out_blocked, gsage_project_fwd_blocked)
  *   ws       : gsage_segment_gather_hidden1_workspace_bytes(N, E, Fo, epilogue) bytes (the rows, the

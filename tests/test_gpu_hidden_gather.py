@@ -214,3 +214,26 @@ def test_model_with_the_recomputed_aggregation_equals_the_plain_path(monkeypatch
     assert_close(emb1, emb0, what="embeddings")
     for a, b, (name, _) in zip(grads1, grads0, model.named_parameters()):
         assert_close(a, b, what=name)
+
+
+def test_nan_feature_is_zeroed_by_relu_on_both_aggregation_paths(monkeypatch):
+    """Pins the library's NaN rule: every forward kernel's ReLU is
+    fmaxf(v, 0) = 0 for v = NaN, and the recompute gather (built with -fno-honor-nans) does the
+    same, where torch's relu passes the NaN on (graphsage.py:134).  So one NaN input feature
+    leaves finite embeddings, identical rows on both paths -- not NaN rows two hops around it."""
+    from graphsage_amd import GraphSAGE, ops
+    from graphsage_amd.synth import memory_features, powerlaw_graph
+    n = 3000
+    ei = powerlaw_graph(n, 10, seed=8).cuda()
+    x = memory_features(n, seed=8).cuda()
+    x[17, 3] = float("nan")
+    torch.manual_seed(1)
+    model = GraphSAGE(7, 64, 64, 2, 0.0).cuda().eval()
+    monkeypatch.setattr(ops, "HIDDEN1_MIN_BYTES", 0)
+    embs = []
+    with torch.no_grad():
+        for recompute in (True, False):
+            monkeypatch.setattr(ops, "HIDDEN1_RECOMPUTE", recompute)
+            embs.append(model(x, ei))
+    assert torch.isfinite(embs[0]).all() and torch.isfinite(embs[1]).all()
+    assert_close(embs[0], embs[1])

@@ -14,6 +14,9 @@ from graphsage_amd import GraphSAGE, TrainStep, shard_bounds  # noqa: E402
 from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph  # noqa: E402
 
 
+DROPOUT = float(os.environ.get("GSAGE_DIST_CHECK_DROPOUT", "0.3"))
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -25,10 +28,16 @@ def main():
     x = memory_features(n, seed=3, device=dev)
     batches = [cooccurrence_batch(ei, n, B, K, seed=10 + s) for s in range(steps)]
     torch.manual_seed(0)
-    model = GraphSAGE(7, 64, 64, 2, 0.0).to(dev)
+    # the reference's dropout (graphsage.py:135): the in-kernel masks of step s must be the same on
+    # every replica, and the same as in the single-process run below
+    model = GraphSAGE(7, 64, 64, 2, DROPOUT).to(dev)
     init = {k: v.clone() for k, v in model.state_dict().items()}
-    ts = TrainStep(model, x, ei)
+    if rank == 1:
+        torch.rand(1000)                 # one rank's CPU generator runs ahead: must not matter
+    ts = TrainStep(model, x, ei)         # base seed: rank 0's draw, broadcast here
     assert ts.world == world
+    if rank != 0:
+        torch.rand(77 * rank)            # ... nor afterwards
     lo, hi = shard_bounds(B, rank, world)
     losses = []
     for t, c, neg in batches:
@@ -36,16 +45,16 @@ def main():
         losses.append(float(stats[0]))
     if rank == 0:
         # single-process run of the same steps on the whole batches (no process group in use)
-        ref_model = GraphSAGE(7, 64, 64, 2, 0.0).to(dev)
+        ref_model = GraphSAGE(7, 64, 64, 2, DROPOUT).to(dev)
         ref_model.load_state_dict(init)
-        ref = TrainStep(ref_model, x, ei)
-        ref.world = 1                                     # the group exists, this stepper ignores it
+        ref = TrainStep(ref_model, x, ei, seed=ts.base_seed, distributed=False)
         ref_losses = [float(ref.step(*b)[0]) for b in batches]
         worst = max(float((a.detach() - b.detach()).abs().max())
                     for a, b in zip(model.parameters(), ref_model.parameters()))
         from graphsage_amd import ops
         print(json.dumps({"world": world, "losses": losses, "ref_losses": ref_losses,
-                          "max_param_diff": worst, "live_rows_used": ops.LIVE_STATS["used"]}),
+                          "max_param_diff": worst, "live_rows_used": ops.LIVE_STATS["used"],
+                          "dropout": DROPOUT}),
               flush=True)
     dist.barrier()
     dist.destroy_process_group()
