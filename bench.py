@@ -283,8 +283,9 @@ def cpu_baseline(args, hidden, out_dim, layers, K, inference=False):
 
 
 def cpu_full_size_configs(K):
-    """the CPU path on BASELINE configs 1 and 2 IN FULL (they fit the host), at the
-    reference's own batch of 1024 pairs; a few seconds in all."""
+    """the CPU path on BASELINE configs 1 and 2 IN FULL (they fit the host) and on
+    config 3 at a reduced step count, at the reference's own batch of 1024 pairs; bounded by time
+    caps (5 s, 5 s, 20 s + one step)."""
     import numpy as np
     import torch
     from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
@@ -292,27 +293,33 @@ def cpu_full_size_configs(K):
     res = []
     z = np.load(os.path.join(ROOT, "tests", "golden", "c1_graph.npz"))
     graphs = [("C1: the reference's default 500-node graph (generator seed 42)",
-               torch.from_numpy(z["edge_index"]), torch.from_numpy(z["features"]).float(), 200),
+               torch.from_numpy(z["edge_index"]), torch.from_numpy(z["features"]).float(), 64, 200, 5.0),
               ("C2: 100k-node/~2M-edge power-law graph", powerlaw_graph(100_000, 20, seed=42),
-               memory_features(100_000, seed=42), 8)]
+               memory_features(100_000, seed=42), 64, 8, 5.0),
+              # C3 at a reduced step count: no warm-up step, at most 2 steps, and the
+              # second only if the first left time under the cap
+              ("C3: 1M-node/~20M-edge power-law graph, SAGE 7->128->128 (reduced step count)",
+               powerlaw_graph(1_000_000, 20, seed=42), memory_features(1_000_000, seed=42), 128, 2, 20.0)]
     threads = torch.get_num_threads()
-    for name, ei, x, max_steps in graphs:
+    for name, ei, x, hidden, max_steps, cap_s in graphs:
         n = x.size(0)
         used = min(threads, 4) if n < 10_000 else threads    # a 500-node step gains nothing beyond
         torch.set_num_threads(used)
         torch.manual_seed(0)
-        model = O.OracleGraphSAGE(7, 64, 64, 2, 0.3).train()
+        model = O.OracleGraphSAGE(7, hidden, hidden, 2, 0.3).train()
         opt = O.make_adam(model)
         batches = [cooccurrence_batch(ei, n, 1024, K, seed=s) for s in range(2)]
-        O.train_step(model, opt, x, ei, *batches[0])
+        if n < 500_000:
+            O.train_step(model, opt, x, ei, *batches[0])
         steps, t0 = 0, time.perf_counter()
-        while steps < max_steps and time.perf_counter() - t0 < 5.0:
+        while steps < max_steps and time.perf_counter() - t0 < cap_s:
             O.train_step(model, opt, x, ei, *batches[steps % 2])
             steps += 1
         dt = (time.perf_counter() - t0) / steps
         res.append({"config": name, "nodes": n, "edges": int(ei.size(1)), "pairs_per_step": 1024,
                     "ms_per_step": dt * 1e3, "pairs_per_s": 1024 / dt, "steps": steps,
                     "cores": used})
+        del model, opt, ei, x
     torch.set_num_threads(threads)
     return res
 
@@ -341,6 +348,99 @@ def run_selftest(args, R):
                           "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "selftest": True}),
               flush=True)
+
+
+# --------------------------------------------------------------- step anatomy (training)
+def live_counts(torch, ei, batch, nodes):
+    """(rows the batch names, edges whose TARGET is such a row): what the touched-row backward
+    walks and what the masked transposed gather fetches.  One batch, outside the timed region."""
+    t, c, neg = batch
+    flag = torch.zeros(nodes, dtype=torch.bool, device=ei.device)
+    flag[t] = True
+    flag[c] = True
+    flag[neg.reshape(-1)] = True
+    rows = int(flag.sum().item())
+    edges = int(flag[ei[1]].sum().item())
+    return rows, edges
+
+
+def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
+    """One entry per bracketed C-ABI call of the step, largest share first.  useful_bytes = what
+    the call's algorithm has to read and write (fp32 rows, int32 CSR, int64 batch ids), per launch:
+
+      segment_gather_F*          4(N+1) + 4E + 4F.E + 4F.N                      
+      segment_gather_F*_skip     4(N+1) + 4E + 4F.Le + 4F.R + 4F.N + N/8        (live edges / rows only)
+      segment_gather_hidden1_F*  4E + 8.slots + 64E (128E: wide training) + 4F.N + pack 72N + 64N
+      project_fwd_8xF            64N read, 4F.N + F.N/8 (sign bits) written
+      project_fwd_FxD            8F.N read, 4D.N + 4N written
+      project_bwd_rows_FxD       R rows of grad, out, agg, x read; R rows of d agg, d x written
+      project_bwd_8xF_weights_only   4F.N (gradient) + F.N/8 (sign bits) + 64N
+      skipgram_fwd               (2+K)(4D + 8).B                                 
+      skipgram_bwd_*             (2+K).4D.B re-gathered + 2(2+K).4D.B read-modify-write
+      touched_rows / zero_rows   8(2+K).B ids + N flag bytes + N/8 mask + 4R list / 4D.R + 4R
+    """
+    train = args.dropout > 0
+    wide_train = train and F > 64
+    slots = N + E // 8                      # bound of the slot list (hidden_gather.hip)
+    models = {
+        "segment_gather_F8": (["seg_gather_vec_k<2, 0, false>"],
+                              "layer-1 mean aggregation of the padded input features (32-byte rows)",
+                              4 * (N + 1) + 4 * E + 32 * E + 32 * N),
+        f"segment_gather_F{F}": ([f"seg_gather_vec_k<{F // 4}, 0, false>"],
+                                 f"mean aggregation over stored {4 * F}-byte rows",
+                                 4 * (N + 1) + 4 * E + 4 * F * E + 4 * F * N),
+        f"segment_gather_F{F}_skip": ([f"seg_gather_vec_k<{F // 4}, 0, true>"],
+                                      "transposed (backward) gather of the layer-2 aggregation; rows "
+                                      "whose gradient is zero are not fetched",
+                                      4 * (N + 1) + 4 * E + 4 * F * Le + 4 * F * R + 4 * F * N + N // 8),
+        f"segment_gather_hidden1_F{F}": ([f"hidden1_gather_k<{F // 32}, {'true' if train else 'false'}>",
+                                          "h1_pack_u_k", "h1_pack_w_k", "h1_hub_combine_k"],
+                                         "layer-2 forward aggregation recomputed from the input layer's "
+                                         "64-byte operand rows on the matrix cores",
+                                         4 * E + 8 * slots + (128 if wide_train else 64) * E + 4 * F * N
+                                         + 72 * N + 64 * N),
+        f"project_fwd_8x{F}": (["project_fwd_k16_k", "sign_flag_k"],
+                               "layer-1 projection + ReLU + dropout, sign bits for the backward",
+                               64 * N + 4 * F * N + F * N // 8),
+        f"project_fwd_{F}x{D}": (["proj64_fwd_k", "pack_fwd_k"] if F == 64 and D == 64 else
+                                 [f"gemm_split_k<{D // 64}>", "split_planes_k"],
+                                 "layer-2 projection + L2 norm", 8 * F * N + 4 * D * N + 4 * N),
+        f"project_bwd_rows_{F}x{D}": (["bwd64_fused_k<2, true>", "reduce_slabs_k", "pack_dx_k", "pack_t_k"],
+                                      "fused layer-2 backward (L2-norm', dX, dW) over the touched rows",
+                                      R * (4 * D * 2 + 4 * F * 2) + R * 8 * F + 4 * R),
+        f"project_bwd_8x{F}_weights_only": (["dw16_mfma_k", "reduce_dw16_k"],
+                                            "layer-1 weight gradients (ReLU'/dropout' from the sign bits)",
+                                            4 * F * N + F * N // 8 + 64 * N),
+        "skipgram_fwd": (["skipgram_fwd_vec_k<1>", "skipgram_finish_k"], "skip-gram loss forward",
+                         (2 + K) * (4 * D + 8) * B),
+        "skipgram_bwd_atomic": (["skipgram_bwd_k"], "skip-gram loss backward (float atomics)",
+                                3 * (2 + K) * 4 * D * B),
+        "skipgram_bwd_det": (["seg_gather_vec_k<16, 2, false>", "radix_scatter_k", "radix_hist_k"],
+                             "skip-gram loss backward (sorted, deterministic)", 3 * (2 + K) * 4 * D * B),
+        "touched_rows": (["rows_mark_k", "rows_count_k", "rows_scan_k", "rows_emit_k"],
+                         "which rows the batch names (mask + sorted list)",
+                         8 * (2 + K) * B + 2 * N + N // 8 + 4 * R),
+        "zero_rows": (["rows_zero_k"], "clear the touched rows of the gradient table", 4 * D * R + 4 * R),
+    }
+    out = []
+    for tag, (launches, ms) in summ.items():
+        kernels, what, useful = models.get(tag, ([], tag, None))
+        traffic, src, stale = None, None, None
+        if not args.nodes and kernels:
+            parts = [measured_traffic(args.workload, k) for k in kernels]
+            got = [p for p in parts if p[0] is not None]
+            if got and parts[0][0] is not None:          # the main kernel must be in the file
+                traffic = sum(p[0] for p in got)
+                src, stale = got[0][1], any(p[2] for p in got)
+        sec = ms * 1e-3
+        out.append({"tag": tag, "kernels": kernels, "what": what, "launches": launches, "ms": ms,
+                    "useful_bytes": useful,
+                    "useful_GBs": useful / sec / 1e9 if useful else None,
+                    "frac_useful": useful / sec / 1e9 / HBM_PEAK_GBS if useful else None,
+                    "traffic": traffic, "traffic_source": src, "traffic_stale": stale,
+                    "frac_traffic": traffic / sec / 1e9 / HBM_PEAK_GBS if traffic else None})
+    out.sort(key=lambda a: -a["ms"] * a["launches"])
+    return out
 
 
 # ------------------------------------------------------------------------------- training
@@ -392,51 +492,41 @@ def run_training(args, R):
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
 
-    # roofline of the dominant operation: the SAGEConv aggregation of the layer-2 forward (SURVEY
-    # 8(d)(ii): algorithmic bytes of K2 / kernel time).  Two kernels can implement it:
-    #   * the plain F=hidden segment gather over the stored activation (seg_gather_vec_k), which
-    #     moves its algorithmic bytes; or
-    #   * the recompute gather (hidden1_gather_k + its two pack kernels and the hub-row combine, one bracket): it fetches the
-    #     64-byte input row of every neighbour and redoes the first layer's projection on the matrix
-    #     cores, so it moves FEWER bytes than the algorithmic count.  It is priced on the same
-    #     algorithmic bytes (the survey's definition: the work done, not the bytes moved), which can
-    #     exceed the HBM peak; `traffic` and `frac_of_peak_on_traffic` say what it really moved.
-    # The masked backward gather likewise fetches fewer bytes than the algorithmic count: timed
-    # under its own tag and reported beside the roofline, never averaged into it.
+    # ---- step anatomy and roofline.  Every C-ABI call of the step is bracketed by HIP events on
+    # the launch stream (ops.KernelTimer).  Per bracket: live mean duration, the bytes it MUST move
+    # for the algorithm it runs (`useful_bytes`, formulas below: DESIGN.md section 3), the HBM bytes
+    # the counters saw for its kernels (`traffic`, profiles/*_pmc_hbm.json: 2 x FETCH_SIZE +
+    # WRITE_SIZE, separate passes), and both as fractions of the 8 TB/s peak.  `roofline` is the
+    # bracket with the largest share of the step; `roofline.survey_model` keeps SURVEY 8(d)'s
+    # figure for the layer-2 forward aggregation (the bytes of a gather of STORED 256-byte rows),
+    # which the recompute gather does not move, as an equivalent rate and a speed-up.
     F = hidden
     summ = timer.summary()
-    plain_l, plain_ms = summ.get(f"segment_gather_F{F}", (0, float("nan")))
-    rec_l, rec_ms = summ.get(f"segment_gather_hidden1_F{F}", (0, float("nan")))
-    skip_launches, skip_ms = summ.get(f"segment_gather_F{F}_skip", (0, float("nan")))
-    alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F
-    recompute = rec_l > 0
-    launches, mean_ms = (rec_l, rec_ms) if recompute else (plain_l, plain_ms)
-    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if launches else None
-    plain_name = f"seg_gather_vec_k<{F // 4}, 0, false>"
-    rec_name = f"hidden1_gather_k<{F // 32}, {'true' if args.dropout > 0 else 'false'}>"
-    kname = rec_name if recompute else plain_name
-    traffic, traffic_src, stale = measured_traffic(args.workload, kname) if not args.nodes \
-        else (None, None, None)
-    if recompute and traffic is not None:
-        # the bracket also holds the kernel that writes the 64-byte rows
-        for extra in ("h1_pack_u_k", "h1_hub_combine_k"):
-            t2, _, _ = measured_traffic(args.workload, extra)
-            traffic = traffic + (t2 or 0.0)
-    roofline = {"bound": "hbm",
-                "kernel": (f"{rec_name} + h1_pack_u_k/h1_pack_w_k/h1_hub_combine_k (layer-2 forward aggregation recomputed from "
-                           f"the input layer's operands), F={F}") if recompute
-                else f"{plain_name} (hub rows included), F={F}",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS if launches else None, "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_stale": stale, "csrc_hash": csrc_hash(),
-                "launches_timed": launches, "mean_ms": mean_ms if launches else None,
-                "algorithmic_bytes": alg_bytes}
-    if recompute:
-        roofline["note"] = ("achieved = SURVEY 8(d) algorithmic bytes of the aggregation / time; the kernel "
-                            "fetches one 128-byte line per neighbour instead of two and recomputes the "
-                            "rows, so frac can exceed 1; its own limit is instruction issue (VALU + MFMA)")
-        roofline["frac_of_peak_on_traffic"] = traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
-        if world == 1 and not args.nodes:
+    live_rows, live_edges = live_counts(torch, ei, batches[0], nodes)
+    anatomy = step_anatomy(args, summ, nodes, E, F, out_dim, B, K, live_rows, live_edges)
+    alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F     # SURVEY 8(d), layer-2 fwd
+    rec = next((a for a in anatomy if a["tag"] == f"segment_gather_hidden1_F{F}"), None)
+    plain = next((a for a in anatomy if a["tag"] == f"segment_gather_F{F}"), None)
+    top = anatomy[0] if anatomy else None
+    roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "csrc_hash": csrc_hash()}
+    if top is not None:
+        roofline.update({
+            "kernel": top["kernels"][0] if top["kernels"] else top["tag"], "what": top["what"],
+            "tag": top["tag"], "launches_timed": top["launches"], "mean_ms": top["ms"],
+            # achieved = algorithmic bytes of THIS kernel's algorithm per launch / its duration
+            "achieved": top["useful_GBs"], "frac": top["frac_useful"],
+            "useful_bytes": top["useful_bytes"], "frac_useful": top["frac_useful"],
+            "traffic": top["traffic"], "frac_traffic": top["frac_traffic"],
+            "traffic_source": top["traffic_source"], "traffic_stale": top["traffic_stale"],
+            "share_of_step": top["ms"] * top["launches"] / args.steps / ms_per_step,
+            "note": "dominant bracket of the step by live HIP-event time; frac = useful bytes / time / "
+                    "peak (never above 1), frac_traffic = counter bytes / time / peak"})
+    agg_l2 = rec or plain
+    if agg_l2 is not None:
+        sm = {"what": "SURVEY 8(d): bytes of the layer-2 forward aggregation as a gather of stored rows",
+              "bytes": alg_bytes, "kernel": agg_l2["kernels"][0], "mean_ms": agg_l2["ms"],
+              "equivalent_GBs": alg_bytes / (agg_l2["ms"] * 1e-3) / 1e9}
+        if rec is not None and world == 1 and not args.nodes:
             # the kernel it replaces, on the same graph: three launches outside the timed steps
             ops.set_kernel_timer(None)
             h = torch.rand(nodes, F, device=dev)
@@ -450,21 +540,19 @@ def run_training(args, R):
             torch.cuda.synchronize()
             pms = e0.elapsed_time(e1) / 3
             del h
+            plain_name = f"seg_gather_vec_k<{F // 4}, 0, false>"
             p_traffic, _, _ = measured_traffic(args.workload, plain_name)
-            roofline["plain_gather"] = {
+            sm["plain_gather"] = {
                 "kernel": f"{plain_name}: the same aggregation over the stored activation "
                           "(GSAGE_HIDDEN1_RECOMPUTE=0), 3 launches outside the timed steps",
-                "mean_ms": pms, "achieved": alg_bytes / (pms * 1e-3) / 1e9,
-                "frac": alg_bytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": p_traffic}
-    if skip_launches:
-        m_traffic, _, _ = measured_traffic(args.workload, f"seg_gather_vec_k<{F // 4}, 0, true>") \
-            if not args.nodes else (None, None, None)
-        roofline["masked_backward_gather"] = {
-            "kernel": f"seg_gather_vec_k<{F // 4},0,masked>: rows whose gradient is zero are not fetched",
-            "launches_timed": skip_launches, "mean_ms": skip_ms, "traffic": m_traffic,
-            # it moves fewer bytes than the algorithmic count, so its rate is quoted on the bytes
-            # the counters saw (same profile file as roofline.traffic)
-            "measured_traffic_GBs": m_traffic / (skip_ms * 1e-3) / 1e9 if m_traffic else None}
+                "mean_ms": pms, "useful_bytes": alg_bytes,
+                "frac_useful": alg_bytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": p_traffic,
+                "frac_traffic": p_traffic / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS if p_traffic else None}
+            sm["speedup_vs_plain_gather"] = pms / agg_l2["ms"]
+        roofline["survey_model"] = sm
+    roofline["kernels"] = anatomy[:8]
+    roofline["bracketed_ms_per_step"] = sum(a["ms"] * a["launches"] for a in anatomy) / args.steps
 
     # the batch the reference would actually train with (config/config.yaml:37, trainer.py:108):
     # a short second timed loop on the same graph, model and harness, eager
@@ -476,6 +564,13 @@ def run_training(args, R):
     # pipe with each fp32 operand split exactly into three bf16 parts (fp32-equivalent results)
     dtype = "f32" if hidden < 128 or os.environ.get("GSAGE_WIDE_GEMM", "")[:1] == "f" else \
         "f32 (wide GEMMs: bf16 MFMA on 3-way split fp32 operands, fp32 accumulate)"
+    if any(a["tag"].startswith("segment_gather_hidden1") for a in anatomy):
+        dtype += ("; the layer-2 forward aggregation recomputes the 16->hidden projection of every "
+                  "gathered row on bf16 MFMA with 3-way split fp32 operands (6 of 9 products, fp32 "
+                  "accumulate: fp32-equivalent)" if dtype != "f32" else
+                  " (storage, accumulation and every GEMM in fp32, except: the layer-2 forward "
+                  "aggregation recomputes the 16->hidden projection of every gathered row on bf16 MFMA "
+                  "with 3-way split fp32 operands, 6 of 9 products, fp32 accumulate: fp32-equivalent)")
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -603,17 +698,18 @@ def run_inference(args, R):
     mfma_floor = issued / (peak * 1e12)
     hbm_floor = gemm_bytes / (HBM_PEAK_GBS * 1e9)
     bound = "mfma" if mfma_floor >= hbm_floor else "hbm"
-    roofline = dict(mfma if bound == "mfma" else hbm)
-    roofline.update({
+    proj = dict(mfma if bound == "mfma" else hbm)
+    proj.update({
         "bound": bound,
         "kernel": f"{kname} ({hidden}->{out_dim} projection; the bracket also holds the weight "
                   "pack/split, microseconds)",
         "floors_ms": {"mfma": mfma_floor * 1e3, "hbm": hbm_floor * 1e3},
         "other_bound": hbm if bound == "mfma" else mfma,
-        "launches_timed": launches, "mean_ms": mean_ms if launches else None,
-        "csrc_hash": csrc_hash()})
+        "launches_timed": launches, "mean_ms": mean_ms if launches else None})
     traffic, traffic_src, stale = measured_traffic("c5", kname) if not args.nodes else (None, None, None)
-    roofline.update({"traffic": traffic, "traffic_source": traffic_src, "traffic_stale": stale})
+    proj.update({"traffic": traffic, "traffic_source": traffic_src, "traffic_stale": stale,
+                 "frac_traffic": traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                 if traffic and launches else None})
     dtype = {"f32": "f32",
              "bf16x3": "f32 (wide GEMMs: bf16 MFMA on 3-way split fp32 operands, fp32 accumulate)",
              "fp16x2": "f32 (wide GEMMs: fp16 MFMA on 2-way split, range-scaled fp32 operands, fp32 "
@@ -621,34 +717,65 @@ def run_inference(args, R):
     F = hidden
     alg_bytes = 4 * (nodes + 1) + 4 * E + 4 * E * F + 4 * nodes * F        # SURVEY 8(d), per layer
     blocked_tag = f"segment_gather_F64x{F // 64}_blocked"
+    per_launch = 1
     if blocked_tag in summ:
         # hidden activations kept as F/64 tables of [N,64]: one layer's aggregation = F/64 launches
         # of the 64-wide gather (bracketed together); priced on the SAME algorithmic bytes as the
         # single 256-wide gather it replaces (the col re-reads of launches 2..4 are not counted)
         gl, gms = summ[blocked_tag]
-        gname = f"{F // 64} x seg_gather_vec_k<16, 0, false> over column-blocked [N,64] tables, F={F}"
+        per_launch = F // 64
+        gkernel = "seg_gather_vec_k<16, 0, false>"
+        gname = f"{F // 64} x {gkernel} over column-blocked [N,64] tables, F={F}"
     else:
         gl, gms = summ.get(f"segment_gather_F{F}", (0, float("nan")))
-        gname = f"seg_gather_vec_k<{F // 4}, 0, false>, F={F}"
+        gkernel = f"seg_gather_vec_k<{F // 4}, 0, false>"
+        gname = f"{gkernel}, F={F}"
     gach = alg_bytes / (gms * 1e-3) / 1e9 if gl else None
-    roofline["gather"] = {"bound": "hbm", "kernel": gname, "achieved": gach, "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": gach / HBM_PEAK_GBS if gl else None,
-                          "launches_timed": gl, "mean_ms": gms if gl else None,
-                          "algorithmic_bytes": alg_bytes}
+    g_traffic, g_src, g_stale = measured_traffic("c5", gkernel) if not args.nodes else (None, None, None)
+    if g_traffic is not None:
+        g_traffic *= per_launch                      # the file holds the mean per kernel launch
+    gather = {"bound": "hbm", "kernel": gname, "achieved": gach, "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": gach / HBM_PEAK_GBS if gl else None,
+              "useful_bytes": alg_bytes, "frac_useful": gach / HBM_PEAK_GBS if gl else None,
+              "traffic": g_traffic, "traffic_source": g_src, "traffic_stale": g_stale,
+              "frac_traffic": g_traffic / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS if g_traffic and gl else None,
+              "launches_timed": gl, "mean_ms": gms if gl else None,
+              "what": "mean aggregation of a 256-wide hidden layer over stored rows (SURVEY 8d bytes)"}
+    # the dominant bracket of the encode by live time is named `roofline`; the other one rides along
+    gather_share = gl * gms if gl else 0.0
+    proj_share = launches * mean_ms if launches else 0.0
+    if gather_share >= proj_share:
+        roofline = dict(gather)
+        roofline["projection"] = proj
+    else:
+        roofline = dict(proj)
+        roofline["gather"] = gather
+    roofline["share_of_step"] = max(gather_share, proj_share) / args.steps / ms
+    roofline["csrc_hash"] = csrc_hash()
     htag = f"segment_gather_hidden1_F{F}"
     if htag in summ:
-        # the first wide aggregation (layer 2) is recomputed from the input layer's operands: priced
-        # on the algorithmic bytes of the gather it replaces (can exceed the peak: it moves fewer)
+        # the first wide aggregation (layer 2) is recomputed from the input layer's operands; its
+        # own bytes: col + slot descriptors + one 64-byte row per neighbour + the output + the pack
         hl, hms = summ[htag]
-        h_traffic, _, _ = measured_traffic("c5", f"hidden1_gather_k<{F // 32}, false>") if not args.nodes \
-            else (None, None, None)
+        hname = f"hidden1_gather_k<{F // 32}, false>"
+        h_traffic = None
+        if not args.nodes:
+            parts = [measured_traffic("c5", k)[0] for k in (hname, "h1_pack_u_k", "h1_hub_combine_k")]
+            h_traffic = sum(p for p in parts if p) if parts[0] else None
+        h_useful = 4 * E + 8 * (nodes + E // 8) + 64 * E + 4 * F * nodes + 136 * nodes
         roofline["gather_recomputed"] = {
-            "bound": "hbm", "kernel": f"hidden1_gather_k<{F // 32}, false> + pack kernels, F={F} (layer 2)",
-            "achieved": alg_bytes / (hms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": alg_bytes / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_timed": hl, "mean_ms": hms,
-            "algorithmic_bytes": alg_bytes, "traffic": h_traffic,
+            "bound": "hbm", "kernel": f"{hname} + pack kernels, F={F} (layer 2)", "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "launches_timed": hl, "mean_ms": hms,
+            "useful_bytes": h_useful, "achieved": h_useful / (hms * 1e-3) / 1e9,
+            "frac": h_useful / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_useful": h_useful / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": h_traffic,
+            "frac_traffic": h_traffic / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS if h_traffic else None,
+            "survey_model": {"bytes": alg_bytes, "equivalent_GBs": alg_bytes / (hms * 1e-3) / 1e9,
+                             "speedup_vs_plain_gather": gms / hms if gl else None,
+                             "what": "SURVEY 8(d) bytes of the gather of stored 1 KiB rows it stands in for"},
             "note": "fetches 64 bytes per neighbour instead of 1 KiB and recomputes the rows on the matrix "
-                    "cores; limited by instruction issue (VALU + MFMA), not by HBM"}
+                    "cores; limited by instruction issue (VALU + MFMA), then by the 128-byte line rate"}
     per_kernel = {k: {"launches": v[0], "mean_ms": v[1]} for k, v in sorted(summ.items())}
     if rank == 0:
         cpu = None

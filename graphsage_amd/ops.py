@@ -55,6 +55,26 @@ class KernelTimer:
 _timer: Optional[KernelTimer] = None
 
 
+class _Bracket:
+    """``with _bracket(tag):`` -- HIP events around the launches inside, if a timer is set."""
+    __slots__ = ("ev",)
+
+    def __init__(self, tag):
+        self.ev = _timer.bracket(tag) if _timer is not None and _timer.enabled else None
+
+    def __enter__(self):
+        if self.ev:
+            self.ev[0].record()
+
+    def __exit__(self, *exc):
+        if self.ev:
+            self.ev[1].record()
+        return False
+
+
+_bracket = _Bracket
+
+
 def set_kernel_timer(timer: Optional[KernelTimer]) -> None:
     global _timer
     _timer = timer
@@ -329,13 +349,14 @@ def project_bwd_rows(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue
         gwl, gwr, gb = torch.empty(Fo, Fi, **f32), torch.empty(Fo, Fi, **f32), torch.empty(Fo, **f32)
         ws_bytes = lib.gsage_project_bwd_workspace_bytes(N, Fi, Fo)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        rc = lib.gsage_project_bwd_rows(grad_out.data_ptr(), _lib.ptr(out), _lib.ptr(rnorm),
-                                        agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), w_r.data_ptr(),
-                                        _lib.ptr(agg_scale), N, Fi, Fo, int(epilogue), float(p),
-                                        grad_agg.data_ptr(), grad_x.data_ptr(), gwl.data_ptr(),
-                                        gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(), ws_bytes,
-                                        live.rows.data_ptr(), live.n_rows.data_ptr(), live.cap,
-                                        _lib.stream_handle())
+        with _bracket(f"project_bwd_rows_{Fi}x{Fo}"):
+            rc = lib.gsage_project_bwd_rows(grad_out.data_ptr(), _lib.ptr(out), _lib.ptr(rnorm),
+                                            agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), w_r.data_ptr(),
+                                            _lib.ptr(agg_scale), N, Fi, Fo, int(epilogue), float(p),
+                                            grad_agg.data_ptr(), grad_x.data_ptr(), gwl.data_ptr(),
+                                            gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(), ws_bytes,
+                                            live.rows.data_ptr(), live.n_rows.data_ptr(), live.cap,
+                                            _lib.stream_handle())
     _lib.check(rc, "gsage_project_bwd_rows")
     return grad_agg, grad_x, gwl, gb, gwr
 
@@ -364,13 +385,14 @@ def project_bwd(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue, p,
             nz = torch.empty((N + 31) // 32, dtype=torch.int32, device=dev)
         if relu_sign is not None and relu_sign.numel() * 8 != lib.gsage_relu_sign_bytes(N, Fo):
             raise ValueError("relu_sign does not belong to a forward of this shape")
-        rc = lib.gsage_project_bwd_ex(grad_out.data_ptr(), _lib.ptr(out), _lib.ptr(rnorm),
-                                      agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), w_r.data_ptr(),
-                                      _lib.ptr(agg_scale), N, Fi, Fo, int(epilogue), float(p),
-                                      _lib.ptr(dpre), _lib.ptr(grad_agg), _lib.ptr(grad_x),
-                                      gwl.data_ptr(), gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(),
-                                      ws_bytes, int(force_generic), _lib.ptr(nz),
-                                      _lib.ptr(relu_sign), _lib.stream_handle())
+        with _bracket(f"project_bwd_{Fi}x{Fo}" + ("" if need_input_grad else "_weights_only")):
+            rc = lib.gsage_project_bwd_ex(grad_out.data_ptr(), _lib.ptr(out), _lib.ptr(rnorm),
+                                          agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), w_r.data_ptr(),
+                                          _lib.ptr(agg_scale), N, Fi, Fo, int(epilogue), float(p),
+                                          _lib.ptr(dpre), _lib.ptr(grad_agg), _lib.ptr(grad_x),
+                                          gwl.data_ptr(), gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(),
+                                          ws_bytes, int(force_generic), _lib.ptr(nz),
+                                          _lib.ptr(relu_sign), _lib.stream_handle())
     _lib.check(rc, "gsage_project_bwd")
     if want_nz_mask:
         return grad_agg, grad_x, gwl, gb, gwr, nz
@@ -408,10 +430,11 @@ def touched_rows(targets, contexts, negatives, N: int) -> LiveRows:
         n_rows = torch.empty(1, dtype=torch.int32, device=dev)
         ws_bytes = lib.gsage_touched_rows_workspace_bytes(N)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        rc = lib.gsage_touched_rows(targets.data_ptr(), contexts.data_ptr(),
-                                    negatives.data_ptr() if K > 0 else None, B, K, N,
-                                    mask.data_ptr(), rows.data_ptr(), cap, n_rows.data_ptr(),
-                                    ws.data_ptr(), ws_bytes, _lib.stream_handle())
+        with _bracket("touched_rows"):
+            rc = lib.gsage_touched_rows(targets.data_ptr(), contexts.data_ptr(),
+                                        negatives.data_ptr() if K > 0 else None, B, K, N,
+                                        mask.data_ptr(), rows.data_ptr(), cap, n_rows.data_ptr(),
+                                        ws.data_ptr(), ws_bytes, _lib.stream_handle())
     _lib.check(rc, "gsage_touched_rows")
     return LiveRows(mask, rows, n_rows, cap, 0, N)
 
@@ -441,7 +464,7 @@ class GradTable:
             return
         if self.live is not None:
             lib = _lib.load()
-            with torch.cuda.device(self.buf.device):
+            with torch.cuda.device(self.buf.device), _bracket("zero_rows"):
                 rc = lib.gsage_zero_rows(self.live.rows.data_ptr(), self.live.n_rows.data_ptr(),
                                          self.live.cap, self.buf.size(1), self.buf.data_ptr(),
                                          _lib.stream_handle())
@@ -472,11 +495,12 @@ def skipgram_fwd(emb, targets, contexts, negatives, scale, norm_b=None, norm_bk=
         stats = torch.empty(8, dtype=torch.float32, device=dev)
         ws_bytes = lib.gsage_skipgram_workspace_bytes(B)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        rc = lib.gsage_skipgram_fwd(emb.data_ptr(), N, D, targets.data_ptr(), contexts.data_ptr(),
-                                    negatives.data_ptr() if K > 0 else None, B, K, float(scale),
-                                    float(norm_b), float(norm_bk), coef.data_ptr(),
-                                    stats.data_ptr(), ws.data_ptr(), ws_bytes,
-                                    _lib.stream_handle())
+        with _bracket("skipgram_fwd"):
+            rc = lib.gsage_skipgram_fwd(emb.data_ptr(), N, D, targets.data_ptr(), contexts.data_ptr(),
+                                        negatives.data_ptr() if K > 0 else None, B, K, float(scale),
+                                        float(norm_b), float(norm_bk), coef.data_ptr(),
+                                        stats.data_ptr(), ws.data_ptr(), ws_bytes,
+                                        _lib.stream_handle())
     _lib.check(rc, "gsage_skipgram_fwd")
     return coef, stats
 
@@ -513,21 +537,23 @@ def skipgram_bwd(emb, targets, contexts, negatives, coef, grad_loss, grad_emb=No
             grad_emb = torch.empty_like(emb)
             ws_bytes = lib.gsage_skipgram_bwd_det_workspace_bytes(N, B, K)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=emb.device)
-            rc = lib.gsage_skipgram_bwd_det(emb.data_ptr(), N, D, targets.data_ptr(),
-                                            contexts.data_ptr(),
-                                            negatives.data_ptr() if K > 0 else None, B, K,
-                                            coef.data_ptr(), grad_loss.data_ptr(),
-                                            grad_emb.data_ptr(), ws.data_ptr(), ws_bytes,
-                                            _lib.stream_handle())
+            with _bracket("skipgram_bwd_det"):
+                rc = lib.gsage_skipgram_bwd_det(emb.data_ptr(), N, D, targets.data_ptr(),
+                                                contexts.data_ptr(),
+                                                negatives.data_ptr() if K > 0 else None, B, K,
+                                                coef.data_ptr(), grad_loss.data_ptr(),
+                                                grad_emb.data_ptr(), ws.data_ptr(), ws_bytes,
+                                                _lib.stream_handle())
         _lib.check(rc, "gsage_skipgram_bwd_det")
         return grad_emb
     with torch.cuda.device(emb.device):
         if grad_emb is None:
             grad_emb = torch.zeros_like(emb)
-        rc = lib.gsage_skipgram_bwd(emb.data_ptr(), N, D, targets.data_ptr(), contexts.data_ptr(),
-                                    negatives.data_ptr() if K > 0 else None, B, K, coef.data_ptr(),
-                                    grad_loss.data_ptr(), grad_emb.data_ptr(),
-                                    _lib.stream_handle())
+        with _bracket("skipgram_bwd_atomic"):
+            rc = lib.gsage_skipgram_bwd(emb.data_ptr(), N, D, targets.data_ptr(), contexts.data_ptr(),
+                                        negatives.data_ptr() if K > 0 else None, B, K, coef.data_ptr(),
+                                        grad_loss.data_ptr(), grad_emb.data_ptr(),
+                                        _lib.stream_handle())
     _lib.check(rc, "gsage_skipgram_bwd")
     return grad_emb
 

@@ -215,6 +215,25 @@ def _torch_sage_gpu(x, ei, conv, n):
         torch.nn.functional.linear(x, conv.lin_r.weight.double())
 
 
+def _hidden_pattern_fp32(m, x, ei, n):
+    """h1 > 0 of the fp32 run (the first layer as GraphSAGE.forward runs it in eval mode; the
+    kernels are deterministic, so this is the model's own hidden activation).  The float64
+    composition takes its ReLU pattern from here: an element whose pre-activation lies within
+    rounding of zero may fall on the other side in float64, and each such flip moves a first-layer
+    weight gradient by one whole term.  With the pattern fixed the comparison is about arithmetic
+    only and every gradient meets the 1e-5 bar."""
+    import torch.nn.functional as F
+    from graphsage_amd import _lib, ops
+    from graphsage_amd.graph import default_cache
+    conv = m.convs[0]
+    x8 = default_cache().padded(x, 8, keep=True)
+    graph = default_cache().get(ei, n)
+    agg1 = ops.aggregate_mean(graph, x8)
+    h1, _ = ops.project_fwd(agg1, x8, F.pad(conv.lin_l.weight, (0, 1)).detach(), conv.lin_l.bias.detach(),
+                            F.pad(conv.lin_r.weight, (0, 1)).detach(), epilogue=_lib.EPI_RELU)
+    return h1 > 0
+
+
 def test_full_size_c4_forward_and_weight_gradients_match_torch_composition():
     """BASELINE C4 (10 M nodes, ~200 M edges, 7->64->64), eval mode: embeddings and the gradients
     of all six parameter tensors for a random linear functional of the embeddings, against the
@@ -231,20 +250,22 @@ def test_full_size_c4_forward_and_weight_gradients_match_torch_composition():
     (emb * probe).sum().backward()
     got = {k: p.grad.clone() for k, p in m.named_parameters()}
     m.zero_grad()
-    h = torch.relu(_torch_sage_gpu(x.double(), ei, m.convs[0], n))
+    pattern = _hidden_pattern_fp32(m, x, ei, n)
+    pre = _torch_sage_gpu(x.double(), ei, m.convs[0], n)
+    flips = (pre > 0) != pattern                              # only where pre is rounding noise
+    assert float(pre[flips].abs().max() if bool(flips.any()) else 0.0) <= 1e-5
+    h = pre * pattern.double()
+    del pre, flips
     want = torch.nn.functional.normalize(_torch_sage_gpu(h, ei, m.convs[1], n), p=2, dim=1)
     del h
     (want * probe.double()).sum().backward()
     err = (emb.detach().double() - want.detach()).abs().max().item()
     assert err <= 2e-6, err                                   # unit-norm rows: absolute = relative
     assert torch.allclose(emb.detach().norm(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
-    # Layer 2 sits behind no ReLU: the oracle bar.  Layer 1's gradients pass the ReLU derivative
-    # of 6.4e8 hidden activations; the few whose pre-activation lies within rounding of 0 take the
-    # other branch in float64, and each such flip moves a weight gradient by one whole term
-    # (~5e-5 here), so that side can only be compared to ~1e-3 of the largest gradient.
+    # all six tensors at the oracle bar (the ReLU pattern is the fp32 run's, see above)
     for k, p in m.named_parameters():
         ref = p.grad.double()
-        tol = (1e-5 if k.startswith("convs.1.") else 1e-3) * float(ref.abs().max())
+        tol = 1e-5 * float(ref.abs().max())
         worst = float((got[k].double() - ref).abs().max())
         assert worst <= tol, (k, worst, tol)
 
@@ -265,7 +286,7 @@ def test_c3_shape_forward_and_weight_gradients_match_float64_composition():
     (emb * probe).sum().backward()
     got = {k: p.grad.clone() for k, p in m.named_parameters()}
     m.zero_grad()
-    h = torch.relu(_torch_sage_gpu(x.double(), ei, m.convs[0], n))
+    h = _torch_sage_gpu(x.double(), ei, m.convs[0], n) * _hidden_pattern_fp32(m, x, ei, n).double()
     want = torch.nn.functional.normalize(_torch_sage_gpu(h, ei, m.convs[1], n), p=2, dim=1)
     del h
     (want * probe.double()).sum().backward()
@@ -273,7 +294,7 @@ def test_c3_shape_forward_and_weight_gradients_match_float64_composition():
     assert err <= 2e-6, err
     for k, p in m.named_parameters():
         ref = p.grad.double()
-        tol = (1e-5 if k.startswith("convs.1.") else 1e-3) * float(ref.abs().max())
+        tol = 1e-5 * float(ref.abs().max())
         worst = float((got[k].double() - ref).abs().max())
         assert worst <= tol, (k, worst, tol)
 
