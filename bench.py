@@ -417,6 +417,15 @@ def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
                                 3 * (2 + K) * 4 * D * B),
         "skipgram_bwd_det": (["seg_gather_vec_k<16, 2, false>", "radix_scatter_k", "radix_hist_k"],
                              "skip-gram loss backward (sorted, deterministic)", 3 * (2 + K) * 4 * D * B),
+        "skipgram_bwd_rows": (["sg_rows_gather_k<16>", "radix_scatter_k<true>", "radix_hist_k", "sg_terms_rows_k",
+                               "rowptr_from_sorted_k"],
+                              "skip-gram loss backward: terms sorted by place in the touched-row list, "
+                              "summed row by row (deterministic, no atomics)",
+                              # terms listed (ids read, 12 B written), three radix passes over (row, source,
+                              # weight): 4 B for the histogram, 12 B read and 12 B written per pass; row
+                              # boundaries; then the sums: one source row per term, one written row per
+                              # listed row
+                              2 * (1 + K) * B * (16 + 12 + 3 * 28 + 4 + 8 + 4 * D) + R * (4 * D + 8)),
         "touched_rows": (["rows_mark_k", "rows_count_k", "rows_scan_k", "rows_emit_k"],
                          "which rows the batch names (mask + sorted list)",
                          8 * (2 + K) * B + 2 * N + N // 8 + 4 * R),
@@ -591,8 +600,9 @@ def run_training(args, R):
                        "pairs": "target = source of a random edge, context = its 1-hop neighbour or "
                                 "(p = 1/2) a 2-hop one, negatives ~ out_degree^0.75",
                        "parallelism": f"replicated graph, pair-sharded dp{world}",
-                       "loss_backward": "deterministic (sorted)" if ops.loss_bwd_deterministic(nodes, B, K)
-                       else "atomic",
+                       "loss_backward": "deterministic (sorted over the touched rows)"
+                       if ops.loss_bwd_rowwise(nodes, out_dim, B, K) else
+                       "deterministic (sorted)" if ops.loss_bwd_deterministic(nodes, B, K) else "atomic",
                        "final_loss": loss},
             "roofline": roofline, "reference_batch": ref_batch, "cpu_baseline": cpu,
         }), flush=True)

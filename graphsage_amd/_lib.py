@@ -47,6 +47,11 @@ SIGNATURES = {
     "gsage_touched_rows_workspace_bytes": (_sz, [_i64]),
     "gsage_touched_rows": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
     "gsage_zero_rows": (C.c_int, [_p, _p, _i64, _i64, _p, _p]),
+    "gsage_touched_rows_ex": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _p, _sz, _p]),
+    "gsage_skipgram_bwd_rows_supported": (C.c_int, [_i64]),
+    "gsage_skipgram_bwd_rows_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "gsage_skipgram_bwd_rows": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p,
+                                          _p, _p, _p, _p, _i64, _p, _sz, _p]),
     "gsage_project_workspace_bytes": (_sz, [_i64, _i64]),
     "gsage_project_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int, _p,
                                     C.c_uint64, C.c_float, _p, _p, _p, C.c_int, _p]),

@@ -184,23 +184,28 @@ __global__ void radix_hist_k(const int *__restrict__ keys, int64_t n, int shift,
   if (t <= mask) counts[(int64_t)t * ntiles + blockIdx.x] = h[t];
 }
 
+// TWO: a second 32-bit payload travels with every item (the loss backward sorts (row, source,
+// weight) triples, so no permutation has to be applied afterwards)
+template <bool TWO>
 __global__ void __launch_bounds__(RS_T)
 radix_scatter_k(const int *__restrict__ kin, const int *__restrict__ vin, int64_t n,
                 int shift, int mask, int width, const int *__restrict__ offs,
-                int64_t ntiles, int *__restrict__ kout, int *__restrict__ vout) {
+                int64_t ntiles, int *__restrict__ kout, int *__restrict__ vout,
+                const int *__restrict__ v2in, int *__restrict__ v2out) {
   __shared__ int whist[RS_T / 64][256];
   const int t = threadIdx.x, lane = gs_lane(), w = t >> 6;
   for (int i = t; i < (RS_T / 64) * 256; i += RS_T) (&whist[0][0])[i] = 0;
   __syncthreads();
 
   const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * RS_WAVE_ITEMS;
-  int k[RS_ROUNDS], v[RS_ROUNDS];
+  int k[RS_ROUNDS], v[RS_ROUNDS], v2[TWO ? RS_ROUNDS : 1];
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
     int64_t idx = wbase + r * 64 + lane;
     bool valid = idx < n;
     k[r] = valid ? kin[idx] : 0;
     v[r] = valid ? vin[idx] : 0;
+    if (TWO) v2[r] = valid ? v2in[idx] : 0;
   }
   // phase 1: per-wave digit histogram
 #pragma unroll
@@ -244,6 +249,7 @@ radix_scatter_k(const int *__restrict__ kin, const int *__restrict__ vin, int64_
       int pos = basev + rank;
       if (kout) kout[pos] = k[r];
       vout[pos] = v[r];
+      if (TWO) v2out[pos] = v2[r];
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -251,43 +257,63 @@ radix_scatter_k(const int *__restrict__ kin, const int *__restrict__ vin, int64_
 
 }  // namespace
 
-// stable sort of (key,val) by key in [0, 2^bits); the sorted values land in vout_final.
-int gs_radix_sort_vals(const int *keys, const int *vals, int64_t n, int bits, int *vout_final,
-                       const GsSortWs &ws, hipStream_t st, const int **sorted_keys) {
+// stable sort of (key,val[,val2]) by key in [0, 2^bits); the sorted values land in vout_final
+// (and v2out_final).  vals2 == nullptr: one payload.
+int gs_radix_sort_vals2(const int *keys, const int *vals, const int *vals2, int64_t n, int bits,
+                        int *vout_final, int *v2out_final, const GsSortWs &ws, int *v2A, int *v2B,
+                        hipStream_t st, const int **sorted_keys) {
   if (sorted_keys) *sorted_keys = keys;
   if (n <= 0) return GSAGE_OK;
   if (bits < 1) bits = 1;
   int passes = (bits + 7) / 8;
   int width = (bits + passes - 1) / passes;
   int64_t ntiles = (n + RS_TILE - 1) / RS_TILE;
-  const int *kin = keys, *vin = vals;
+  const int *kin = keys, *vin = vals, *v2in = vals2;
   for (int p = 0; p < passes; ++p) {
     int shift = p * width;
     int mask = (1 << width) - 1;
     bool last = (p == passes - 1);
     int *kout = (last && !sorted_keys) ? nullptr : ((p & 1) ? ws.kB : ws.kA);
     int *vout = last ? vout_final : ((p & 1) ? ws.vB : ws.vA);
+    int *v2out = last ? v2out_final : ((p & 1) ? v2B : v2A);
     hipLaunchKernelGGL(radix_hist_k, dim3((unsigned)ntiles), dim3(RS_T), 0, st, kin, n, shift,
                        mask, ws.counts, ntiles);
     int64_t ncounts = (int64_t)(mask + 1) * ntiles;
     int rc = gs_exclusive_scan(ws.counts, ncounts, ws.counts, ws.bsum, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(radix_scatter_k, dim3((unsigned)ntiles), dim3(RS_T), 0, st, kin, vin, n,
-                       shift, mask, width, ws.counts, ntiles, kout, vout);
+    if (vals2)
+      hipLaunchKernelGGL(radix_scatter_k<true>, dim3((unsigned)ntiles), dim3(RS_T), 0, st, kin, vin, n,
+                         shift, mask, width, ws.counts, ntiles, kout, vout, v2in, v2out);
+    else
+      hipLaunchKernelGGL(radix_scatter_k<false>, dim3((unsigned)ntiles), dim3(RS_T), 0, st, kin, vin, n,
+                         shift, mask, width, ws.counts, ntiles, kout, vout, (const int *)nullptr,
+                         (int *)nullptr);
     GSAGE_CHECK_LAUNCH();
     kin = kout;
     vin = vout;
+    v2in = v2out;
   }
   if (sorted_keys) *sorted_keys = kin;
   return GSAGE_OK;
+}
+
+int gs_radix_sort_vals(const int *keys, const int *vals, int64_t n, int bits, int *vout_final,
+                       const GsSortWs &ws, hipStream_t st, const int **sorted_keys) {
+  return gs_radix_sort_vals2(keys, vals, nullptr, n, bits, vout_final, nullptr, ws, nullptr, nullptr,
+                             st, sorted_keys);
 }
 
 namespace {
 // position p in [0, n] starts rows (key[p-1], key[p]] (key[-1] = -1, key[n] = nrows); the lanes
 // of a wave fill each such range together, so a long run of empty rows is written coalesced
 __global__ void __launch_bounds__(256)
-rowptr_from_sorted_k(const int *__restrict__ skey, int64_t n, int64_t nrows, int *__restrict__ rp) {
+rowptr_from_sorted_k(const int *__restrict__ skey, int64_t n, int64_t nrows, int *__restrict__ rp,
+                     const int *__restrict__ nrows_dev) {
   const int lane = gs_lane();
+  // the row count may live on the device (a per-batch CSR over a row list whose length the host
+  // does not know): rows beyond it are not wanted, so the end of the keys closes row *nrows_dev
+  // instead of filling rowptr up to the host's bound
+  if (nrows_dev && *nrows_dev < nrows) nrows = *nrows_dev;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t base = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); base <= n; base += stride) {
     const int64_t p = base + lane;
@@ -295,8 +321,15 @@ rowptr_from_sorted_k(const int *__restrict__ skey, int64_t n, int64_t nrows, int
     if (p <= n) {
       prev = p > 0 ? skey[p - 1] : -1;
       cur = p < n ? skey[p] : (int)nrows;
+      if (cur < prev) cur = prev;      // (a sentinel key above a device-side row count: no new row)
     }
-    uint64_t m = __ballot(cur > prev);
+    // most boundaries start ONE row (dense keys: the per-batch CSR of the loss backward has a
+    // boundary every 2.4 positions); those lanes write their few entries themselves and only the
+    // long runs of empty rows are filled by the whole wave
+    const int gap = cur - prev;
+    if (gap > 0 && gap <= 4)
+      for (int k = prev + 1; k <= cur; ++k) rp[k] = (int)p;
+    uint64_t m = __ballot(gap > 4);
     while (m) {
       const int l = __ffsll((unsigned long long)m) - 1;
       m &= m - 1;
@@ -318,9 +351,9 @@ inv_deg_from_rowptr_k(const int *__restrict__ rp, int64_t N, float *__restrict__
 }  // namespace
 
 int gs_rowptr_from_sorted(const int *sorted_keys, int64_t n, int64_t nrows, int *rowptr,
-                          hipStream_t st) {
+                          hipStream_t st, const int *nrows_dev) {
   hipLaunchKernelGGL(rowptr_from_sorted_k, dim3(gs_grid(n + 1, 256, 1 << 20)), dim3(256), 0, st,
-                     sorted_keys, n, nrows, rowptr);
+                     sorted_keys, n, nrows, rowptr, nrows_dev);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }

@@ -410,7 +410,7 @@ rows_scan_k(int *__restrict__ block_sums, int nblocks, int *__restrict__ n_rows)
 
 __global__ void __launch_bounds__(RC_BLOCK)
 rows_emit_k(const uint32_t *__restrict__ mask, int64_t nwords, const int *__restrict__ block_off,
-            int *__restrict__ rows, int64_t cap) {
+            int *__restrict__ rows, int64_t cap, int *__restrict__ word_prefix) {
   __shared__ int wsum[RC_BLOCK / 64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int64_t i = (int64_t)blockIdx.x * RC_BLOCK + t;
@@ -426,6 +426,9 @@ rows_emit_k(const uint32_t *__restrict__ mask, int64_t nwords, const int *__rest
   __syncthreads();
   int64_t pos = block_off[blockIdx.x] + inc - c;
   for (int k = 0; k < w; ++k) pos += wsum[k];
+  // place in the list of the word's first set bit: the rank of row r is
+  // word_prefix[r >> 5] + popcount(mask[r >> 5] & ((1 << (r & 31)) - 1))
+  if (word_prefix && i < nwords) word_prefix[i] = (int)pos;
   const int row0 = (int)(i << 5);
   while (m) {
     const int b = __ffs(m) - 1;
@@ -448,6 +451,154 @@ rows_zero_k(const int *__restrict__ rows, const int *__restrict__ n_rows, int64_
     const int64_t r = rows[e / d4];
     *(float4 *)(buf + r * D + (e % d4) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+}
+
+// ------------------------------------- deterministic backward over the touched rows only
+// The sorted form above scales with N (its row boundaries cover all N rows, its radix keys have
+// log2 N bits, its gather writes N rows): at 10 M rows and 2^20 pairs it loses to the atomics.
+// With the touched-row list in hand the key of a term is the PLACE of its destination row in that
+// list (word prefix + popcount below the row's bit: two L2-resident reads), the per-batch CSR has
+// one row per listed row, and the gather writes only those rows of grad_emb -- each exactly once,
+// with its whole sum, in term order: bitwise reproducible, nothing to zero beforehand.
+__global__ void __launch_bounds__(256)
+sg_terms_rows_k(const int64_t *__restrict__ tg, const int64_t *__restrict__ ctx,
+                const int64_t *__restrict__ neg, int64_t B, int64_t K, int64_t N,
+                const float *__restrict__ coef, const float *__restrict__ grad_loss,
+                const uint32_t *__restrict__ mask, const int *__restrict__ word_prefix, int sentinel,
+                int *__restrict__ key, int *__restrict__ tsrc, float *__restrict__ tw) {
+  const int64_t M = B * 2 * (1 + K);
+  const float g = *grad_loss;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < M; e += stride) {
+    int64_t b = e / (2 * (1 + K));
+    int s = (int)(e % (2 * (1 + K)));
+    int64_t dst, src;
+    int r;
+    sg_term(tg, ctx, neg, K, b, s, dst, src, r);
+    const bool bad = (uint64_t)dst >= (uint64_t)N || (uint64_t)src >= (uint64_t)N;
+    int k = sentinel;                          // sorted last, belongs to no listed row
+    if (!bad) {
+      const uint32_t m = mask[dst >> 5];
+      const int bit = (int)(dst & 31);
+      k = word_prefix[dst >> 5] + __popc(m & ((1u << bit) - 1u));
+      if (!((m >> bit) & 1u) || k >= sentinel) k = sentinel;   // (a row the mask does not name)
+    }
+    // (row, source, weight) travel through the sort together: it is stable, so the terms of a
+    // row stay in term order without a term number
+    key[e] = k;
+    tsrc[e] = bad ? 0 : (int)src;
+    tw[e] = bad ? 0.f : coef[b * (1 + K) + r] * g;
+  }
+}
+
+// out[rows[r], :] = sum over the terms p of listed row r of w[p] * emb[col[p], :], r < *n_rows.
+// A wave takes G = 64 / LPR consecutive listed rows as ONE flat run of terms (a listed row has 2.4
+// terms on average at the headline batch): 64 terms per trip whatever the row boundaries, each
+// lane group fetching every G-th one with NB loads in flight and adding it to the accumulator of
+// the row it belongs to; one full-wave store at the end.  Term order within a row is the sort's
+// (stable: term number), the lane group and trip a term lands in follow from its position alone.
+template <int LPR>
+__global__ void __launch_bounds__(256)
+sg_rows_gather_k(const int *__restrict__ rowptr, const int *__restrict__ col,
+                 const float *__restrict__ w, const float *__restrict__ emb,
+                 const int *__restrict__ rows, const int *__restrict__ n_rows, int64_t cap,
+                 int64_t D, float *__restrict__ out) {
+  constexpr int G = 64 / LPR;
+  constexpr int NB = 4;
+  const int lane = gs_lane();
+  const int slot = lane / LPR, sub = lane % LPR;
+  int64_t n = *n_rows;
+  if (n > cap) n = cap;
+  const int64_t rg = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G;
+  if (rg >= n) return;
+  int b[G + 1];
+#pragma unroll
+  for (int i = 0; i <= G; ++i) b[i] = rowptr[rg + i < n ? rg + i : n];
+  const int64_t my_row = rg + slot < n ? rows[rg + slot] : -1;
+  float4 acc[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int pend = b[G];
+  for (int pc = b[0]; pc < pend; pc += 64) {
+    const int pl = pc + lane;
+    const bool have = pl < pend;
+    const int cv = col[have ? pl : pend - 1];
+    const float wv = have ? w[pl] : 0.f;
+    int rv = 0;
+#pragma unroll
+    for (int i = 1; i < G; ++i) rv += pl >= b[i] ? 1 : 0;
+    int cnt = pend - pc;
+    if (cnt > 64) cnt = 64;
+    const int steps = (cnt + G - 1) / G;
+    for (int s = 0; s < steps; s += NB) {
+      float4 r[NB];
+      float wt[NB];
+      int ri[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int j = ((s + k) * G + slot) & 63;
+        const bool valid = (s + k) * G + slot < cnt;
+        const int c = __shfl(cv, j, 64);
+        wt[k] = __shfl(wv, j, 64);
+        const int rj = __shfl(rv, j, 64);      // (every lane takes part: lane j may itself be past the end)
+        ri[k] = valid ? rj : -1;
+        // slots past the end re-read the last term's row (cached) and are answered by no accumulator
+        r[k] = *(const float4 *)(emb + (int64_t)c * D + sub * 4);
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const bool hit = ri[k] == i;          // select the product, not the weight: 0 * inf is NaN
+          acc[i].x += hit ? r[k].x * wt[k] : 0.f; acc[i].y += hit ? r[k].y * wt[k] : 0.f;
+          acc[i].z += hit ? r[k].z * wt[k] : 0.f; acc[i].w += hit ? r[k].w * wt[k] : 0.f;
+        }
+      }
+    }
+  }
+  float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    float4 t = acc[i];
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+      t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64);
+      t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
+    }
+    if (slot == i) keep = t;
+  }
+  if (my_row >= 0) *(float4 *)(out + my_row * D + sub * 4) = keep;
+}
+
+struct RowsLayout {
+  size_t total, o_key, o_src, o_w, o_kA, o_vA, o_wA, o_kB, o_vB, o_wB, o_counts, o_bsum, o_rowptr,
+      o_col, o_cw;
+  int64_t M;
+};
+
+RowsLayout rows_layout(int64_t rows_cap, int64_t B, int64_t K) {
+  RowsLayout L;
+  L.M = B * 2 * (1 + K);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += gs_align_up(bytes ? bytes : 4, 256);
+    return o;
+  };
+  const size_t m4 = (size_t)L.M * 4;
+  const int64_t ntiles = (L.M + GS_RS_TILE - 1) / GS_RS_TILE;
+  const int64_t ncounts = 256 * (ntiles > 0 ? ntiles : 1);
+  const int64_t scan_n = ncounts > (rows_cap + 2) ? ncounts : (rows_cap + 2);
+  L.o_key = take(m4); L.o_src = take(m4); L.o_w = take(m4);
+  L.o_kA = take(m4); L.o_vA = take(m4); L.o_wA = take(m4);
+  L.o_kB = take(m4); L.o_vB = take(m4); L.o_wB = take(m4);
+  L.o_counts = take((size_t)ncounts * 4);
+  L.o_bsum = take((size_t)((scan_n + GS_SCAN_CH - 1) / GS_SCAN_CH + 1) * 4);
+  L.o_rowptr = take((size_t)(rows_cap + 2) * 4);
+  L.o_col = take(m4);
+  L.o_cw = take(m4);
+  L.total = off;
+  return L;
 }
 
 // Grid of the (grid-stride) forward kernels: never more workgroups than the chip holds at once.
@@ -569,6 +720,15 @@ extern "C" int gsage_touched_rows(const int64_t *targets, const int64_t *context
                                   const int64_t *negatives, int64_t B, int64_t K, int64_t N,
                                   uint32_t *mask, int32_t *rows, int64_t rows_cap, int32_t *n_rows,
                                   void *ws, size_t ws_bytes, gsage_stream_t stream) {
+  return gsage_touched_rows_ex(targets, contexts, negatives, B, K, N, mask, rows, rows_cap, n_rows,
+                               nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int gsage_touched_rows_ex(const int64_t *targets, const int64_t *contexts,
+                                     const int64_t *negatives, int64_t B, int64_t K, int64_t N,
+                                     uint32_t *mask, int32_t *rows, int64_t rows_cap,
+                                     int32_t *n_rows, int32_t *word_prefix, void *ws,
+                                     size_t ws_bytes, gsage_stream_t stream) {
   if (N <= 0 || B <= 0 || K < 0 || !targets || !contexts || !mask || !rows || !n_rows || !ws ||
       rows_cap <= 0)
     return GSAGE_ERR_INVALID_ARG;
@@ -590,7 +750,7 @@ extern "C" int gsage_touched_rows(const int64_t *targets, const int64_t *context
   hipLaunchKernelGGL(rows_scan_k, dim3(1), dim3(1024), 0, st, block_sums, nblocks, n_rows);
   GSAGE_CHECK_LAUNCH();
   hipLaunchKernelGGL(rows_emit_k, dim3(nblocks), dim3(RC_BLOCK), 0, st, mask, nwords, block_sums,
-                     rows, rows_cap);
+                     rows, rows_cap, word_prefix);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
 }
@@ -673,4 +833,63 @@ extern "C" int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D,
   rc = gs_list_long_rows(rowptr, N, longs, L.long_cap, nlong, st);
   if (rc) return rc;
   return gsage_segment_gather_ew(rowptr, col, w, emb, N, D, grad_emb, longs, nlong, stream);
+}
+
+extern "C" int gsage_skipgram_bwd_rows_supported(int64_t D) { return (D == 64 || D == 128) ? 1 : 0; }
+
+extern "C" size_t gsage_skipgram_bwd_rows_workspace_bytes(int64_t rows_cap, int64_t B, int64_t K) {
+  if (rows_cap <= 0 || B <= 0 || K < 0) return 0;
+  return rows_layout(rows_cap, B, K).total;
+}
+
+extern "C" int gsage_skipgram_bwd_rows(const float *emb, int64_t N, int64_t D,
+                                       const int64_t *targets, const int64_t *contexts,
+                                       const int64_t *negatives, int64_t B, int64_t K,
+                                       const float *coef, const float *grad_loss, float *grad_emb,
+                                       const uint32_t *live_mask, const int32_t *word_prefix,
+                                       const int32_t *rows, const int32_t *n_rows, int64_t rows_cap,
+                                       void *ws, size_t ws_bytes, gsage_stream_t stream) {
+  if (N <= 0 || D <= 0 || B <= 0 || K < 0 || !emb || !targets || !contexts || !coef ||
+      !grad_loss || !grad_emb || !live_mask || !word_prefix || !rows || !n_rows || !ws ||
+      rows_cap <= 0)
+    return GSAGE_ERR_INVALID_ARG;
+  if (K > 0 && !negatives) return GSAGE_ERR_INVALID_ARG;
+  if (!gsage_skipgram_bwd_rows_supported(D)) return GSAGE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)emb | (uintptr_t)grad_emb) & 15) != 0) return GSAGE_ERR_UNSUPPORTED;
+  const RowsLayout L = rows_layout(rows_cap, B, K);
+  if (L.M >= (1ll << 31) - 1 || N >= (1ll << 31) - 64 || rows_cap >= (1ll << 31) - 2)
+    return GSAGE_ERR_UNSUPPORTED;
+  if (ws_bytes < L.total) return GSAGE_ERR_WORKSPACE;
+  hipStream_t st = gs_stream(stream);
+  char *b = (char *)ws;
+  int *key = (int *)(b + L.o_key), *tsrc = (int *)(b + L.o_src);
+  float *tw = (float *)(b + L.o_w);
+  GsSortWs sw{(int *)(b + L.o_kA), (int *)(b + L.o_vA), (int *)(b + L.o_kB), (int *)(b + L.o_vB),
+              (int *)(b + L.o_counts), (int *)(b + L.o_bsum)};
+  int *rowptr = (int *)(b + L.o_rowptr);
+  int *col = (int *)(b + L.o_col);
+  float *w = (float *)(b + L.o_cw);
+  // keys are places in the list, 0 .. rows_cap - 1, and the sentinel rows_cap
+  hipLaunchKernelGGL(sg_terms_rows_k, dim3(gs_grid(L.M, 256, 1 << 16)), dim3(256), 0, st, targets,
+                     contexts, negatives, B, K, N, coef, grad_loss, live_mask, word_prefix,
+                     (int)rows_cap, key, tsrc, tw);
+  GSAGE_CHECK_LAUNCH();
+  int bits = 0;
+  while ((1ll << bits) <= rows_cap) ++bits;
+  const int *skey = nullptr;
+  int rc = gs_radix_sort_vals2(key, tsrc, (const int *)tw, L.M, bits, col, (int *)w, sw,
+                               (int *)(b + L.o_wA), (int *)(b + L.o_wB), st, &skey);
+  if (rc) return rc;
+  rc = gs_rowptr_from_sorted(skey, L.M, rows_cap, rowptr, st, n_rows);
+  if (rc) return rc;
+  const int G = D == 64 ? 4 : 2;
+  const unsigned grid = (unsigned)((rows_cap + 4 * G - 1) / (4 * G));
+  if (D == 64)
+    hipLaunchKernelGGL((sg_rows_gather_k<16>), dim3(grid), dim3(256), 0, st, (const int *)rowptr,
+                       (const int *)col, (const float *)w, emb, rows, n_rows, rows_cap, D, grad_emb);
+  else
+    hipLaunchKernelGGL((sg_rows_gather_k<32>), dim3(grid), dim3(256), 0, st, (const int *)rowptr,
+                       (const int *)col, (const float *)w, emb, rows, n_rows, rows_cap, D, grad_emb);
+  GSAGE_CHECK_LAUNCH();
+  return GSAGE_OK;
 }

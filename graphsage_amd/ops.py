@@ -399,14 +399,22 @@ def project_bwd(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue, p,
     return grad_agg, grad_x, gwl, gb, gwr
 
 
+ROWWISE_KEEPS_ROWS = os.environ.get("GSAGE_ROWWISE_KEEPS_ROWS", "1") != "0"
+
+
 class LiveRows:
     """The rows of an [N, D] gradient that may be non-zero: bit mask + ascending list + count
     (all on the device), and the version counter of the tensor they describe."""
-    __slots__ = ("mask", "rows", "n_rows", "cap", "version", "num_rows")
+    __slots__ = ("mask", "rows", "n_rows", "cap", "version", "num_rows", "word_prefix", "consumed",
+                 "rowwise", "outside_undefined")
 
-    def __init__(self, mask, rows, n_rows, cap, version, num_rows):
+    def __init__(self, mask, rows, n_rows, cap, version, num_rows, word_prefix=None):
         self.mask, self.rows, self.n_rows, self.cap = mask, rows, n_rows, cap
         self.version, self.num_rows = version, num_rows
+        self.word_prefix = word_prefix     # place in `rows` of each mask word's first set bit
+        self.consumed = False              # set by a consumer that read the listed rows only
+        self.rowwise = False               # the listed rows were written in full (row-wise backward)
+        self.outside_undefined = False     # rows outside the list hold a former step's values
 
 
 # The gradient of the loss is non-zero only on the rows the pair batch names.  The loss backward
@@ -426,17 +434,19 @@ def touched_rows(targets, contexts, negatives, N: int) -> LiveRows:
     cap = max(1, min(N, (2 + K) * B))
     with torch.cuda.device(dev):
         mask = torch.empty((N + 31) // 32, dtype=torch.int32, device=dev)
+        wpre = torch.empty((N + 31) // 32, dtype=torch.int32, device=dev)
         rows = torch.empty(cap, dtype=torch.int32, device=dev)
         n_rows = torch.empty(1, dtype=torch.int32, device=dev)
         ws_bytes = lib.gsage_touched_rows_workspace_bytes(N)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _bracket("touched_rows"):
-            rc = lib.gsage_touched_rows(targets.data_ptr(), contexts.data_ptr(),
-                                        negatives.data_ptr() if K > 0 else None, B, K, N,
-                                        mask.data_ptr(), rows.data_ptr(), cap, n_rows.data_ptr(),
-                                        ws.data_ptr(), ws_bytes, _lib.stream_handle())
+            rc = lib.gsage_touched_rows_ex(targets.data_ptr(), contexts.data_ptr(),
+                                           negatives.data_ptr() if K > 0 else None, B, K, N,
+                                           mask.data_ptr(), rows.data_ptr(), cap, n_rows.data_ptr(),
+                                           wpre.data_ptr(), ws.data_ptr(), ws_bytes,
+                                           _lib.stream_handle())
     _lib.check(rc, "gsage_touched_rows")
-    return LiveRows(mask, rows, n_rows, cap, 0, N)
+    return LiveRows(mask, rows, n_rows, cap, 0, N, wpre)
 
 
 class GradTable:
@@ -446,23 +456,39 @@ class GradTable:
     x 64).  Only for an owner that knows the gradient has one consumer and is not kept
     (TrainStep): a leaf's ``.grad`` would alias the buffer."""
 
-    def __init__(self):
+    def __init__(self, keep_rows: bool = False):
+        """``keep_rows``: the owner vouches that the gradient's consumer is a layer of this
+        package (which reads through the row list, or repairs the rest itself: SAGELayerFunction),
+        so a row-wise loss backward may leave its rows in the table instead of clearing them."""
         self.buf: Optional[torch.Tensor] = None
         self.live: Optional[LiveRows] = None
         self.dirty = False
+        self.keep_rows = bool(keep_rows) and ROWWISE_KEEPS_ROWS
+        # rows outside the current list may hold a former step's values (the row-wise loss
+        # backward overwrites its listed rows and a consumer that reads listed rows only needs
+        # nothing cleared): a user that needs zeros elsewhere gets a full zero-fill first
+        self.stale = False
 
-    def take(self, like: torch.Tensor) -> torch.Tensor:
+    def take(self, like: torch.Tensor, overwrites_rows: bool = False) -> torch.Tensor:
+        """``overwrites_rows``: the caller writes every listed row in full and its consumer will
+        read listed rows only (gsage_skipgram_bwd_rows), so nothing has to be zero."""
         if self.buf is None or self.buf.shape != like.shape or self.buf.device != like.device:
             self.buf = torch.zeros_like(like)
-        elif self.dirty:                 # the last user never released it: start clean
-            self.buf.zero_()
+            self.stale = False
+        elif (self.dirty or self.stale) and not overwrites_rows:
+            self.buf.zero_()             # the last user never released it / left rows behind
+            self.stale = False
         self.dirty, self.live = True, None
         return self.buf
 
     def release(self) -> None:
         if self.buf is None or not self.dirty:
             return
-        if self.live is not None:
+        if self.live is not None and self.live.consumed and self.live.rowwise and self.keep_rows:
+            # the listed rows were written in full and read through the list: leave them, the next
+            # row-wise step overwrites its own rows and never looks at these
+            self.stale = True
+        elif self.live is not None:
             lib = _lib.load()
             with torch.cuda.device(self.buf.device), _bracket("zero_rows"):
                 rc = lib.gsage_zero_rows(self.live.rows.data_ptr(), self.live.n_rows.data_ptr(),
@@ -472,6 +498,8 @@ class GradTable:
         else:
             self.buf.zero_()
         self.dirty, self.live = False, None
+
+
 
 
 def live_rows_worthwhile(N: int, D: int, B: int, K: int) -> bool:
@@ -514,6 +542,44 @@ def skipgram_fwd(emb, targets, contexts, negatives, scale, norm_b=None, norm_bk=
 LOSS_BWD_MODE = os.environ.get("GSAGE_LOSS_BWD", "auto")
 if LOSS_BWD_MODE not in ("auto", "atomic", "det"):
     raise ValueError(f"GSAGE_LOSS_BWD must be auto, atomic or det, not {LOSS_BWD_MODE!r}")
+# A third form where the touched-row list exists (live_rows_worthwhile): sorted and summed over
+# the LISTED rows only (gsage_skipgram_bwd_rows) -- deterministic like "det", without its costs
+# that scale with N.  "auto" takes it whenever the list is built; GSAGE_LOSS_BWD_ROWS=0 keeps
+# the atomics there.
+LOSS_BWD_ROWS = os.environ.get("GSAGE_LOSS_BWD_ROWS", "1") != "0"
+
+
+def loss_bwd_rowwise(N: int, D: int, B: int, K: int, deterministic: Optional[bool] = None) -> bool:
+    """Does the loss backward of this shape run row-wise over the touched rows?"""
+    if not live_rows_worthwhile(N, D, B, K) or D % 4 != 0:
+        return False
+    if deterministic is False or (deterministic is None and LOSS_BWD_MODE == "atomic"):
+        return False
+    if not LOSS_BWD_ROWS and deterministic is None and LOSS_BWD_MODE == "auto":
+        return False
+    return bool(_lib.load().gsage_skipgram_bwd_rows_supported(D))
+
+
+def skipgram_bwd_rows(emb, targets, contexts, negatives, coef, grad_loss, grad_emb, live: LiveRows):
+    """gsage_skipgram_bwd_rows: writes the listed rows of ``grad_emb`` (each in full, fixed term
+    order), touches no other row."""
+    lib = _lib.load()
+    N, D = emb.shape
+    B = targets.numel()
+    K = coef.shape[1] - 1
+    with torch.cuda.device(emb.device):
+        ws_bytes = lib.gsage_skipgram_bwd_rows_workspace_bytes(live.cap, B, K)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=emb.device)
+        with _bracket("skipgram_bwd_rows"):
+            rc = lib.gsage_skipgram_bwd_rows(emb.data_ptr(), N, D, targets.data_ptr(),
+                                             contexts.data_ptr(),
+                                             negatives.data_ptr() if K > 0 else None, B, K,
+                                             coef.data_ptr(), grad_loss.data_ptr(), grad_emb.data_ptr(),
+                                             live.mask.data_ptr(), live.word_prefix.data_ptr(),
+                                             live.rows.data_ptr(), live.n_rows.data_ptr(), live.cap,
+                                             ws.data_ptr(), ws_bytes, _lib.stream_handle())
+    _lib.check(rc, "gsage_skipgram_bwd_rows")
+    return grad_emb
 
 
 def loss_bwd_deterministic(N: int, B: int, K: int) -> bool:
@@ -605,11 +671,20 @@ class SAGELayerFunction(torch.autograd.Function):
                 and _lib.load().gsage_project_bwd_rows_supported(x.size(1), w_l.size(0))):
             # the loss backward listed the rows of grad_out that can be non-zero: walk only those
             LIVE_STATS["used"] += 1
+            live.consumed = True
             grad_agg, grad_x, gwl, gb, gwr = project_bwd_rows(
                 grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p, live)
             grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x,
                                         live_mask=live.mask)
             return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None
+        if live is not None and live.outside_undefined:
+            # a persistent gradient table whose unlisted rows were left from an earlier step, and
+            # this backward cannot go through the row list: rebuild the dense gradient (rare path)
+            n_live = int(live.n_rows.item())
+            idx = live.rows[:min(n_live, live.cap)].long()
+            dense = torch.zeros_like(grad_out)
+            dense[idx] = grad_out[idx]
+            grad_out = dense
         grad_agg, grad_x, gwl, gb, gwr, nz = project_bwd(
             grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p,
             need_x, ctx.force_generic, want_nz_mask=True, relu_sign=sign)
@@ -650,14 +725,26 @@ class SkipGramFunction(torch.autograd.Function):
         K = coef.shape[1] - 1
         N, B = emb.size(0), targets.numel()
         want_live = live_rows_worthwhile(N, emb.size(1), B, K)
+        rowwise = loss_bwd_rowwise(N, emb.size(1), B, K, ctx.deterministic)
         det = ctx.deterministic if ctx.deterministic is not None else loss_bwd_deterministic(N, B, K)
-        table = ctx.grad_table if (want_live and not det and emb.size(1) % 4 == 0) else None
-        grad_emb = skipgram_bwd(emb, targets, contexts, negatives, coef, g,
-                                grad_emb=table.take(emb) if table is not None else None,
-                                deterministic=det)
+        live = touched_rows(targets, contexts, negatives, N) if want_live else None
+        if rowwise:
+            # sorted sums over the listed rows: every listed row written once and in full
+            table = ctx.grad_table
+            if table is not None:
+                live.outside_undefined = table.stale and table.keep_rows
+                grad_emb = table.take(emb, overwrites_rows=table.keep_rows)
+            else:
+                grad_emb = torch.zeros_like(emb)
+            skipgram_bwd_rows(emb, targets, contexts, negatives, coef, g, grad_emb, live)
+            live.rowwise = True
+        else:
+            table = ctx.grad_table if (want_live and not det and emb.size(1) % 4 == 0) else None
+            grad_emb = skipgram_bwd(emb, targets, contexts, negatives, coef, g,
+                                    grad_emb=table.take(emb) if table is not None else None,
+                                    deterministic=det)
         if want_live:
             # rows outside the batch are exactly zero in grad_emb: tell the consumer which
-            live = touched_rows(targets, contexts, negatives, N)
             live.version = grad_emb._version
             try:                         # a fresh attribute each step on the persistent buffer
                 grad_emb._gsage_live = live

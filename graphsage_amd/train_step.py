@@ -76,8 +76,9 @@ class TrainStep:
         if loss_fn is None and features.is_cuda:
             # the embedding gradient of a step has one consumer (the model's last layer) and is
             # not kept: build it in a persistent table that is cleared row-wise, not zero-filled
+            from .graphsage import GraphSAGE
             from .ops import GradTable
-            self.loss_fn.grad_table = GradTable()
+            self.loss_fn.grad_table = GradTable(keep_rows=isinstance(model, GraphSAGE))
         self.flat = FlatParams(model)
         # capturable: the step counter lives on the device, so the optimiser can sit inside a
         # captured HIP graph (capture_step below) as well as run eagerly

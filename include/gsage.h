@@ -340,6 +340,13 @@ int gsage_touched_rows(const int64_t *targets, const int64_t *contexts, const in
                        gsage_stream_t stream);
 int gsage_zero_rows(const int32_t *rows, const int32_t *n_rows, int64_t rows_cap, int64_t D,
                     float *buf, gsage_stream_t stream);
+/* The same, also leaving word_prefix[(N+31)/32] (nullable): the place in `rows` of each mask
+ * word's first set bit, so that rank(r) = word_prefix[r >> 5] + popcount(mask[r >> 5] below bit
+ * r & 31) for every listed row r (what gsage_skipgram_bwd_rows keys its terms by). */
+int gsage_touched_rows_ex(const int64_t *targets, const int64_t *contexts,
+                          const int64_t *negatives, int64_t B, int64_t K, int64_t N, uint32_t *mask,
+                          int32_t *rows, int64_t rows_cap, int32_t *n_rows, int32_t *word_prefix,
+                          void *ws, size_t ws_bytes, gsage_stream_t stream);
 
 /* K4 for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers
  * that must not (or cannot) call hipMalloc or bring a workspace -- code under HIP graph capture,
@@ -372,6 +379,24 @@ int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D, const int64_t
                            const int64_t *contexts, const int64_t *negatives, int64_t B,
                            int64_t K, const float *coef, const float *grad_loss,
                            float *grad_emb, void *ws, size_t ws_bytes, gsage_stream_t stream);
+
+/* K5 without atomics over the TOUCHED ROWS ONLY (same autograd step of loss.py:97-103 as
+ * gsage_skipgram_bwd_det).  The terms are keyed by the place of their destination row in the list
+ * gsage_touched_rows_ex made of this batch (live_mask, word_prefix, rows, n_rows, rows_cap), so
+ * the sort keys have log2(rows_cap) bits instead of log2 N, the per-batch CSR has one row per
+ * listed row, and only the listed rows of grad_emb [N,D] are written -- each once, with its whole
+ * sum, terms in pair order: bitwise reproducible.  Rows outside the list are NOT touched (they
+ * are zero by definition; a consumer either masks them, gsage_segment_gather_live /
+ * gsage_project_bwd_rows, or hands in a buffer that is zero there).  D = 64 or 128
+ * (gsage_skipgram_bwd_rows_supported).  ws: gsage_skipgram_bwd_rows_workspace_bytes(rows_cap, B, K). */
+int gsage_skipgram_bwd_rows_supported(int64_t D);
+size_t gsage_skipgram_bwd_rows_workspace_bytes(int64_t rows_cap, int64_t B, int64_t K);
+int gsage_skipgram_bwd_rows(const float *emb, int64_t N, int64_t D, const int64_t *targets,
+                            const int64_t *contexts, const int64_t *negatives, int64_t B,
+                            int64_t K, const float *coef, const float *grad_loss, float *grad_emb,
+                            const uint32_t *live_mask, const int32_t *word_prefix,
+                            const int32_t *rows, const int32_t *n_rows, int64_t rows_cap, void *ws,
+                            size_t ws_bytes, gsage_stream_t stream);
 
 /* ----------------------------------------------------- feeder: random walks and pair windows
  * gsage_random_walks replaces RandomWalkGenerator.generate_all_walks (src/walks/generator.py:

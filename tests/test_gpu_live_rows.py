@@ -161,10 +161,14 @@ def test_backward_through_model_uses_the_list_and_matches_dense_and_oracle():
     assert ops.LIVE_STATS["used"] == before
 
 
-def test_train_step_grad_table_stays_zero_and_matches_dense_path():
-    """TrainStep builds d(loss)/d(emb) in a persistent table that is cleared row-wise after the
-    backward: parameters after three steps equal the run with the hand-over off (zero-filled
-    gradient, dense kernels), and the table is all zero between steps."""
+@pytest.mark.parametrize("rowwise", [False, True])
+def test_train_step_grad_table_matches_dense_path(rowwise):
+    """TrainStep builds d(loss)/d(emb) in a persistent table.  With the atomic loss backward the
+    table is cleared row-wise after the backward and is all zero between steps; with the row-wise
+    (sorted, deterministic) backward the listed rows are overwritten in full and the layer reads
+    through the list, so nothing is cleared and the table is merely marked stale.  Either way the
+    parameters after three steps equal the run with the hand-over off (zero-filled gradient,
+    dense kernels)."""
     from graphsage_amd import GraphSAGE, TrainStep, ops
     from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
     n, b, k = 30_000, 1500, 5
@@ -172,7 +176,9 @@ def test_train_step_grad_table_stays_zero_and_matches_dense_path():
     x = memory_features(n, seed=42).cuda()
     batches = [cooccurrence_batch(ei, n, b, k, seed=20 + i) for i in range(3)]
     outs = []
+    was = ops.LOSS_BWD_ROWS
     try:
+        ops.LOSS_BWD_ROWS = rowwise
         for live_on in (True, False):
             ops.LIVE_ROWS = live_on
             torch.manual_seed(0)
@@ -183,11 +189,40 @@ def test_train_step_grad_table_stays_zero_and_matches_dense_path():
                 tab = ts.loss_fn.grad_table
                 if live_on:
                     assert tab.buf is not None and not tab.dirty
-                    assert float(tab.buf.abs().max()) == 0.0
+                    if rowwise:
+                        assert tab.stale
+                    else:
+                        assert float(tab.buf.abs().max()) == 0.0 and not tab.stale
             outs.append([p.detach().clone() for p in m.parameters()])
     finally:
-        ops.LIVE_ROWS = True
+        ops.LIVE_ROWS, ops.LOSS_BWD_ROWS = True, was
     for a, d in zip(*outs):
+        assert_close(a, d, rtol=1e-5, floor=2e-6)
+
+
+def test_stale_gradient_table_is_repaired_when_the_row_list_cannot_be_used():
+    """After a row-wise step the table's unlisted rows hold the former step's values.  A backward
+    that cannot go through the list (here: the hand-over switched off between loss and layer)
+    must see zeros there: SAGELayerFunction rebuilds the dense gradient."""
+    from graphsage_amd import GraphSAGE, TrainStep, ops
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    n, b, k = 30_000, 1500, 5
+    ei = powerlaw_graph(n, 10, seed=42).cuda()
+    x = memory_features(n, seed=42).cuda()
+    batches = [cooccurrence_batch(ei, n, b, k, seed=40 + i) for i in range(3)]
+    finals = []
+    try:
+        for sabotage in (False, True):
+            torch.manual_seed(0)
+            m = GraphSAGE(7, 64, 64, 2, 0.0).cuda()
+            ts = TrainStep(m, x, ei)
+            for i, bt in enumerate(batches):
+                ops.SKIP_ZERO_ROWS = not (sabotage and i == 2)   # the layer refuses the list in step 3
+                ts.step(*bt)
+            finals.append([p.detach().clone() for p in m.parameters()])
+    finally:
+        ops.SKIP_ZERO_ROWS = True
+    for a, d in zip(*finals):
         assert_close(a, d, rtol=1e-5, floor=2e-6)
 
 

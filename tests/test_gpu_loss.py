@@ -206,3 +206,97 @@ def test_full_size_c4_loss_properties():
     want += (cf.unsqueeze(2) * emb[t].double().unsqueeze(1)).sum((0, 1)) # terms added to c / negatives
     got = det.double().sum(0)
     assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("n,d,b,k,hot", [(50_000, 64, 4096, 5, False), (3000, 64, 3000, 5, True),
+                                         (20_000, 128, 1000, 3, False), (700, 64, 50, 7, False),
+                                         (64, 64, 7, 0, False), (33, 64, 1, 5, False)])
+def test_rowwise_backward_over_the_touched_rows(n, d, b, k, hot):
+    """gsage_skipgram_bwd_rows: the sorted sums over the LISTED rows only.  Listed rows equal the
+    oracle's gradient (autograd through loss.py:97-136's op sequence) and the full sorted form;
+    every other row of the buffer is left exactly as it was (NaN here); two runs agree bit for
+    bit.  `hot`: one target shared by every pair (a listed row with b*(1+k) terms)."""
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(n + b)
+    emb = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).requires_grad_()
+    t = torch.full((b,), 5, dtype=torch.int64) if hot else torch.randint(0, n, (b,), generator=g)
+    c = torch.randint(0, n, (b,), generator=g)
+    neg = torch.randint(0, n, (b, k), generator=g)
+    if k > 0:
+        O.skipgram_loss(emb, t, c, neg, 5.0).backward()
+    else:
+        (-torch.nn.functional.logsigmoid((emb[t] * emb[c]).sum(1) * 5.0).mean()).backward()
+    e, tt, cc, nn_ = emb.detach().cuda(), t.cuda(), c.cuda(), neg.cuda()
+    coef, _ = ops.skipgram_fwd(e, tt, cc, nn_, 5.0)
+    one = torch.ones((), device="cuda")
+    live = ops.touched_rows(tt, cc, nn_, n)
+    cnt = int(live.n_rows.item())
+    rows = live.rows[:cnt].long()
+    # the word prefix is the rank of each word's first listed row
+    words = (n + 31) // 32
+    bits = torch.zeros(words * 32, dtype=torch.int64, device="cuda")
+    bits[rows] = 1
+    want_pre = torch.cumsum(bits.view(words, 32).sum(1), 0) - bits.view(words, 32).sum(1)
+    assert torch.equal(live.word_prefix.long(), want_pre)
+    outs = []
+    for _ in range(2):
+        buf = torch.full((n, d), float("nan"), device="cuda")
+        ops.skipgram_bwd_rows(e, tt, cc, nn_, coef, one, buf, live)
+        outs.append(buf)
+    assert torch.equal(outs[0][rows], outs[1][rows])                    # bitwise reproducible
+    untouched = torch.ones(n, dtype=torch.bool, device="cuda")
+    untouched[rows] = False
+    assert bool(torch.isnan(outs[0][untouched]).all())                  # not written at all
+    got = torch.zeros(n, d, device="cuda")
+    got[rows] = outs[0][rows]
+    assert_close(got, emb.grad, rtol=1e-5, floor=2e-6, what="row-wise vs oracle")
+    det = ops.skipgram_bwd(e, tt, cc, nn_, coef, one, deterministic=True)
+    assert_close(got, det, rtol=1e-5, floor=2e-6, what="row-wise vs sorted")
+
+
+def test_rowwise_backward_ignores_out_of_range_pairs():
+    from graphsage_amd import ops
+    emb = torch.randn(40, 64).cuda()
+    t = torch.tensor([1, 2, 3]).cuda()
+    c = torch.tensor([3, 40, 4]).cuda()                         # pair 1 has a bad context id
+    neg = torch.tensor([[1, 2], [3, 4], [5, -1]]).cuda()        # pair 2 has a bad negative
+    coef, stats = ops.skipgram_fwd(emb, t, c, neg, 5.0)
+    assert stats[7].item() != 0
+    one = torch.ones((), device="cuda")
+    live = ops.touched_rows(t, c, neg, 40)
+    buf = torch.zeros(40, 64, device="cuda")
+    ops.skipgram_bwd_rows(emb, t, c, neg, coef, one, buf, live)
+    a = ops.skipgram_bwd(emb, t, c, neg, coef, one, deterministic=False)
+    assert torch.isfinite(buf).all()
+    assert_close(buf, a, rtol=1e-5, floor=2e-6)
+
+
+def test_full_size_c4_rowwise_backward():
+    """C4 sizes (10 M x 64 table, 2^20 pairs, K = 5): the row-wise sums against the full sorted
+    form and the atomics, untouched rows untouched, analytic column sums, bitwise repeatable."""
+    from graphsage_amd import ops
+    from graphsage_amd.synth import cooccurrence_batch, powerlaw_graph
+    n, d, b, k = 10_000_000, 64, 1 << 20, 5
+    g = torch.Generator(device="cuda").manual_seed(3)
+    emb = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g), dim=1)
+    ei = powerlaw_graph(n, 20, seed=42, device="cuda")
+    t, c, neg = cooccurrence_batch(ei, n, b, k, seed=1001)              # the benchmark's batches
+    del ei
+    coef, _ = ops.skipgram_fwd(emb, t, c, neg, 5.0)
+    one = torch.ones((), device="cuda")
+    live = ops.touched_rows(t, c, neg, n)
+    cnt = int(live.n_rows.item())
+    rows = live.rows[:cnt].long()
+    a = torch.zeros(n, d, device="cuda")
+    ops.skipgram_bwd_rows(emb, t, c, neg, coef, one, a, live)
+    b2 = torch.full((n, d), 7.0, device="cuda")
+    ops.skipgram_bwd_rows(emb, t, c, neg, coef, one, b2, live)
+    assert torch.equal(a[rows], b2[rows])
+    b2[rows] = 7.0
+    assert bool((b2 == 7.0).all())                                      # nothing else written
+    del b2
+    det = ops.skipgram_bwd(emb, t, c, neg, coef, one, deterministic=True)
+    scale = float(det.abs().max())
+    assert float((a - det).abs().max()) <= 2e-6 * scale
+    atom = ops.skipgram_bwd(emb, t, c, neg, coef, one, deterministic=False)
+    assert float((a - atom).abs().max()) <= 1e-5 * scale

@@ -184,6 +184,30 @@ def test_whole_step_bitwise_reproducible_with_deterministic_loss():
     assert torch.equal(finals[0], finals[1])
 
 
+def test_default_step_is_bitwise_reproducible_where_the_row_list_exists():
+    """The configuration class of the benchmark's headline (batch small against the table, so the
+    loss backward runs row-wise over the touched rows; default SkipGramLoss, dropout 0.3 from the
+    in-kernel hash, persistent gradient table left stale between steps): no atomics anywhere, two
+    runs from the same state end in bit-identical parameters."""
+    from graphsage_amd import GraphSAGE, TrainStep, ops
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    n, b, k = 200_000, 16384, 5
+    assert ops.loss_bwd_rowwise(n, 64, b, k)
+    ei = powerlaw_graph(n, 20, seed=42, device="cuda")
+    x = memory_features(n, seed=42, device="cuda")
+    batches = [cooccurrence_batch(ei, n, b, k, seed=s) for s in range(4)]
+    finals = []
+    for run in range(2):
+        torch.manual_seed(0)
+        m = GraphSAGE(7, 64, 64, 2, 0.3).cuda()
+        ts = TrainStep(m, x, ei, seed=99)
+        for bt in batches:
+            ts.step(*bt)
+        assert ts.loss_fn.grad_table.stale
+        finals.append(torch.cat([p.detach().flatten() for p in m.parameters()]).clone())
+    assert torch.equal(finals[0], finals[1])
+
+
 def test_full_size_c2_properties():
     """C2 (100k nodes, ~2M edges): unit norms, no NaN/Inf, determinism of the forward, and
     agreement with the oracle run on the same inputs (the oracle finishes in ~1 s here)."""
