@@ -535,36 +535,44 @@ extern "C" size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_
          gs_align_up((size_t)h1_piece_cap(E) * (size_t)Fo * sizeof(float), 256) + 256;
 }
 
-extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *col,
-                                            const float *inv_deg, const float *agg1, const float *x8,
-                                            const float *w_l, const float *b_l, const float *w_r,
-                                            int64_t N, int64_t Fo, int epilogue, float p,
-                                            const float *h1, const uint64_t *relu_sign, float *out,
-                                            int out_blocked, void *ws, size_t ws_bytes,
-                                            gsage_stream_t stream) {
-  if (N < 0 || E < 0 || !groups || !inv_deg || !agg1 || !x8 || !w_l || !b_l || !w_r || !out || !ws)
+// u_rows given: the table u[j] is the caller's (left by gsage_project_fwd_u, or by an earlier call),
+// agg1 / x8 / h1 / relu_sign are not read and the workspace holds only planes, partial rows, counter
+static int hidden1_impl(const void *groups, int64_t E, const int32_t *col, const float *inv_deg,
+                        const float *agg1, const float *x8, const float *u_rows, const float *w_l,
+                        const float *b_l, const float *w_r, int64_t N, int64_t Fo, int epilogue,
+                        float p, const float *h1, const uint64_t *relu_sign, float *out,
+                        int out_blocked, void *ws, size_t ws_bytes, gsage_stream_t stream) {
+  if (N < 0 || E < 0 || !groups || !inv_deg || !w_l || !b_l || !w_r || !out || !ws)
     return GSAGE_ERR_INVALID_ARG;
+  if (!u_rows && (!agg1 || !x8)) return GSAGE_ERR_INVALID_ARG;
   if (N >= ((int64_t)1 << 26)) return GSAGE_ERR_UNSUPPORTED;
   if (!gsage_segment_gather_hidden1_supported(Fo, epilogue)) return GSAGE_ERR_UNSUPPORTED;
   const bool train = epilogue == GSAGE_EPI_RELU_DROPOUT;
-  if (train && (!(p >= 0.f && p < 1.f) || (!h1 && !relu_sign))) return GSAGE_ERR_INVALID_ARG;
+  if (train && !(p >= 0.f && p < 1.f)) return GSAGE_ERR_INVALID_ARG;
+  if (train && !u_rows && !h1 && !relu_sign) return GSAGE_ERR_INVALID_ARG;
   if (out_blocked && Fo % 64 != 0) return GSAGE_ERR_UNSUPPORTED;
-  if ((((uintptr_t)agg1 | (uintptr_t)x8 | (uintptr_t)h1 | (uintptr_t)ws) & 15) != 0) return GSAGE_ERR_UNSUPPORTED;
-  if (ws_bytes < gsage_segment_gather_hidden1_workspace_bytes(N, E, Fo, epilogue)) return GSAGE_ERR_WORKSPACE;
+  if ((((uintptr_t)agg1 | (uintptr_t)x8 | (uintptr_t)h1 | (uintptr_t)ws | (uintptr_t)u_rows) & 15) != 0)
+    return GSAGE_ERR_UNSUPPORTED;
+  const size_t need = u_rows ? gsage_segment_gather_hidden1_u_workspace_bytes(E, Fo)
+                             : gsage_segment_gather_hidden1_workspace_bytes(N, E, Fo, epilogue);
+  if (ws_bytes < need) return GSAGE_ERR_WORKSPACE;
   // 32-bit byte offsets into the row table
   if ((uint64_t)N * h1_urow_bytes(Fo, epilogue) > ((uint64_t)1 << 32)) return GSAGE_ERR_UNSUPPORTED;
   if (N == 0) return GSAGE_OK;     // (col may be NULL: a graph without edges has nothing to index)
   hipStream_t st = gs_stream(stream);
   GsCarver carve(ws);
-  float *U = carve.take<float>((size_t)N * (h1_urow_bytes(Fo, epilogue) / 4));
+  const float *U = u_rows;
+  if (!u_rows) U = carve.take<float>((size_t)N * (h1_urow_bytes(Fo, epilogue) / 4));
   uint16_t *planes = carve.take<uint16_t>((size_t)(3 * Fo * 16));
   float *part = carve.take<float>((size_t)h1_piece_cap(E) * (size_t)Fo);
   int *counter = carve.take<int>(4);
   if (!gs_zero_async(counter, 4 * sizeof(int), st)) return GSAGE_ERR_LAUNCH;
   hipLaunchKernelGGL(h1_pack_w_k, dim3(gs_grid(Fo * 16, 256, 16)), dim3(256), 0, st, w_l, b_l, w_r,
                      (int)Fo, planes);
-  hipLaunchKernelGGL(h1_pack_u_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, agg1, x8, N,
-                     train ? 1 : 0, (int)(Fo / 64), h1, (const unsigned long long *)relu_sign, U);
+  if (!u_rows)
+    hipLaunchKernelGGL(h1_pack_u_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, agg1, x8, N,
+                       train ? 1 : 0, (int)(Fo / 64), h1, (const unsigned long long *)relu_sign,
+                       const_cast<float *>(U));
   GSAGE_CHECK_LAUNCH();
   const unsigned grid = H1_GRID_WAVES / H1_WG_WAVES;
   const H1Groups g = h1_carve(const_cast<void *>(groups), N, E);
@@ -587,4 +595,35 @@ extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const
                      (const float *)part, inv_deg, scale, (int)Fo, out, blk);
   GSAGE_CHECK_LAUNCH();
   return GSAGE_OK;
+}
+
+extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *col,
+                                            const float *inv_deg, const float *agg1, const float *x8,
+                                            const float *w_l, const float *b_l, const float *w_r,
+                                            int64_t N, int64_t Fo, int epilogue, float p,
+                                            const float *h1, const uint64_t *relu_sign, float *out,
+                                            int out_blocked, void *ws, size_t ws_bytes,
+                                            gsage_stream_t stream) {
+  if (!agg1 || !x8) return GSAGE_ERR_INVALID_ARG;
+  return hidden1_impl(groups, E, col, inv_deg, agg1, x8, nullptr, w_l, b_l, w_r, N, Fo, epilogue, p,
+                      h1, relu_sign, out, out_blocked, ws, ws_bytes, stream);
+}
+
+extern "C" size_t gsage_hidden1_u_row_bytes(int64_t Fo, int epilogue) { return h1_urow_bytes(Fo, epilogue); }
+
+extern "C" size_t gsage_segment_gather_hidden1_u_workspace_bytes(int64_t E, int64_t Fo) {
+  if (E < 0 || Fo <= 0) return 0;
+  return gs_align_up(h1_planes_bytes(Fo), 256) +
+         gs_align_up((size_t)h1_piece_cap(E) * (size_t)Fo * sizeof(float), 256) + 256;
+}
+
+extern "C" int gsage_segment_gather_hidden1_u(const void *groups, int64_t E, const int32_t *col,
+                                              const float *inv_deg, const float *u_rows,
+                                              const float *w_l, const float *b_l, const float *w_r,
+                                              int64_t N, int64_t Fo, int epilogue, float p, float *out,
+                                              int out_blocked, void *ws, size_t ws_bytes,
+                                              gsage_stream_t stream) {
+  if (!u_rows) return GSAGE_ERR_INVALID_ARG;
+  return hidden1_impl(groups, E, col, inv_deg, nullptr, nullptr, u_rows, w_l, b_l, w_r, N, Fo,
+                      epilogue, p, nullptr, nullptr, out, out_blocked, ws, ws_bytes, stream);
 }

@@ -906,7 +906,10 @@ __global__ void __launch_bounds__(512, 1) gemm_half_k(GemmArgs a, const uint16_t
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1;
   const int K = a.K, K1 = a.K1;
-  const int ny = a.Ncols / BN, nysh = ny - 1, nk = K >> 5;     // ny is 1 or 2 (launcher)
+  // ny is 1 or 2 (the launcher's half_shape_ok admits nothing else), and for exactly those two
+  // values ny - 1 is both log2(ny), the shift that takes a tile number to its row block, and
+  // the mask that takes it to its column block
+  const int ny = a.Ncols / BN, nysh = ny - 1, nk = K >> 5;
   const int ntiles = (int)(((a.M + BM - 1) / BM) * ny);
   const int64_t plane_elems = (int64_t)a.Ncols * K;
   const float sa = ctl->sa;
@@ -1650,7 +1653,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
                   const float *__restrict__ wt /* [16][Fo] */, int64_t N, int Fo, EpiArgs e,
-                  float *__restrict__ out, uint64_t *__restrict__ sign, int64_t out_blk = 0) {
+                  float *__restrict__ out, uint64_t *__restrict__ sign, int64_t out_blk = 0,
+                  float *__restrict__ U = nullptr, int urow = 16) {
+  // U (optional): the rows u[j] = [agg[j][0..6], m_lo, x[j][0..6], m_hi] that the recompute gather
+  // of the NEXT layer fetches (hidden_gather.hip; `urow` floats per row: 16, or 32 when the masks
+  // of further 64-column groups ride behind the row).  m = the 64 keep-and-positive bits of this
+  // workgroup's column group, in the order the ballots below come in; this kernel already holds
+  // the row's operands and those ballots, so no separate pack pass over agg / x / sign is needed.
   constexpr int K16_PP = 68;                   // pitch of the 16 x 64 output patch
   __shared__ __align__(16) float patches[4][16 * K16_PP];
   float *patch = patches[threadIdx.x >> 6];
@@ -1723,6 +1732,7 @@ project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
     // covers 4 whole 256-byte row segments instead (v4b: 4.9 TB/s).
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) *(float4 *)(patch + rl * K16_PP + 16 * nt + 4 * q) = v[nt];
+    uint32_t m_lo = 0u, m_hi = 0u;                    // (U, training) the mask words of row rl
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rr = 4 * i + q;                       // q = lane >> 4: 4 rows per instruction
@@ -1736,16 +1746,39 @@ project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
         amx = max(max(amx, __float_as_uint(o.x) & 0x7FFFFFFFu), __float_as_uint(o.y) & 0x7FFFFFFFu);
         amx = max(max(amx, __float_as_uint(o.z) & 0x7FFFFFFFu), __float_as_uint(o.w) & 0x7FFFFFFFu);
       }
-      if (sign) {
+      if (sign || (U && e.mode == GSAGE_EPI_RELU_DROPOUT)) {
         // which outputs are positive, for the backward's ReLU'/dropout' (gsage_relu_sign_words):
         // per group of 4 rows and column block four 64-bit words, word c bit l = component c of
         // lane l's float4 -- the lane layout dw16_mfma_k reads the rows back in
         const unsigned long long b0 = __ballot(o.x > 0.f), b1 = __ballot(o.y > 0.f);
         const unsigned long long b2 = __ballot(o.z > 0.f), b3 = __ballot(o.w > 0.f);
-        const unsigned long long mine = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-        const int64_t grp = (r0 >> 2) + i;
-        if (lane < 4 && r0 + 4 * i < N)
-          sign[((int64_t)blockIdx.y * ((N + 3) >> 2) + grp) * 4 + lane] = mine;
+        if (sign) {
+          const unsigned long long mine = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+          const int64_t grp = (r0 >> 2) + i;
+          if (lane < 4 && r0 + 4 * i < N)
+            sign[((int64_t)blockIdx.y * ((N + 3) >> 2) + grp) * 4 + lane] = mine;
+        }
+        if (U && (rl >> 2) == i) {
+          // row rl = 4 i + (rl & 3) of the block: its bits are the 16-bit field (rl & 3) of each word
+          const int sh = 16 * (rl & 3);
+          m_lo = (uint32_t)((b0 >> sh) & 0xFFFFull) | ((uint32_t)((b1 >> sh) & 0xFFFFull) << 16);
+          m_hi = (uint32_t)((b2 >> sh) & 0xFFFFull) | ((uint32_t)((b3 >> sh) & 0xFFFFull) << 16);
+        }
+      }
+    }
+    if (U && live) {
+      float *u = U + row * urow;
+      if (blockIdx.y == 0) {
+        // lane (rl, q) holds quarter q of [agg | x] of row rl: 16 lanes x 16 bytes = the 64-byte row,
+        // a wave = 16 consecutive rows = 1 KiB contiguous (2 KiB-strided halves when urow = 32)
+        float4 cu = c;
+        if (q == 1) cu.w = __uint_as_float(m_lo);
+        if (q == 3) cu.w = __uint_as_float(m_hi);
+        *(float4 *)(u + 4 * q) = cu;
+      } else if (urow > 16) {
+        // column group g >= 1: its two mask words behind the row (low words at float 16, high at 20)
+        if (q == 1) ((uint32_t *)u)[16 + blockIdx.y - 1] = m_lo;
+        if (q == 3) ((uint32_t *)u)[20 + blockIdx.y - 1] = m_hi;
       }
     }
   }
@@ -2156,7 +2189,9 @@ static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
                             int64_t Fo, int epilogue, const uint8_t *keep_mask,
                             uint64_t seed, float p, float *out, float *rnorm, void *wpack,
                             int force_generic, uint64_t *relu_sign, int64_t in_blk, int64_t out_blk,
-                            const uint32_t *amax_in, uint32_t *amax_out, gsage_stream_t stream) {
+                            const uint32_t *amax_in, uint32_t *amax_out, gsage_stream_t stream,
+                            float *u_rows = nullptr, int *u_written = nullptr) {
+  if (u_written) *u_written = 0;
   if (N < 0 || Fi <= 0 || Fo <= 0 || !agg || !x || !w_l || !b_l || !w_r || !out || !wpack)
     return GSAGE_ERR_INVALID_ARG;
   if (epilogue < GSAGE_EPI_NONE || epilogue > GSAGE_EPI_L2NORM) return GSAGE_ERR_INVALID_ARG;
@@ -2216,6 +2251,7 @@ static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
     a.M = N; a.K1 = fi; a.K = 2 * fi; a.N1 = fo; a.Ncols = fo; a.epi = e;
     a.a_blk = in_blk; a.c_blk = out_blk;
     if (force_generic == 0 && (fo == 128 || fo == 256)) return launch_wide(fo, a, wpack, Fi, Fo, amax_in, st);
+    if (amax_out) return GSAGE_ERR_UNSUPPORTED;     // gemm_rows_k does not publish max |out|
     return launch_gemm_bn(fo, a, st);
   }
   hipLaunchKernelGGL(pack_t_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
@@ -2224,9 +2260,16 @@ static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
       ((((uintptr_t)agg | (uintptr_t)x | (uintptr_t)out | (uintptr_t)b_l | (uintptr_t)keep_mask) & 15) == 0)) {
     int g16 = gs_grid(N, 64, 256 * 8);
     const bool relu = epilogue == GSAGE_EPI_RELU || epilogue == GSAGE_EPI_RELU_DROPOUT;
+    // the rows for the next layer's recompute gather, if wanted: its shapes and epilogues only
+    float *U = (u_rows && relu && (fo == 64 || fo == 128 || fo == 256) && (((uintptr_t)u_rows) & 15) == 0)
+                   ? u_rows : nullptr;
+    const int urow = (epilogue == GSAGE_EPI_RELU_DROPOUT && fo > 64) ? 32 : 16;
     hipLaunchKernelGGL(project_fwd_k16_k, dim3(g16, fo / 64), dim3(256), 0, st, agg, x, wp, N, fo, e,
-                       out, relu ? relu_sign : nullptr, out_blk);
+                       out, relu ? relu_sign : nullptr, out_blk, U, urow);
     sign_written = relu;
+    if (U && u_written) *u_written = 1;
+  } else if (amax_out) {
+    return GSAGE_ERR_UNSUPPORTED;     // the kernels below do not publish max |out| (unaligned operands)
   } else if (2 * Fi <= 16 && (Fo <= 64 || (Fo % 64 == 0 && epilogue != GSAGE_EPI_L2NORM)))
     hipLaunchKernelGGL((project_fwd_smallk_k<16>), dim3(grid, (fo + 63) / 64), dim3(256), 0, st, agg,
                        x, wp, N, fi, fo, e, out);
@@ -2249,6 +2292,17 @@ extern "C" int gsage_project_fwd_ex(const float *agg, const float *x, const floa
                                     gsage_stream_t stream) {
   return project_fwd_impl(agg, x, w_l, b_l, w_r, N, Fi, Fo, epilogue, keep_mask, seed, p, out, rnorm,
                           wpack, force_generic, relu_sign, 0, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int gsage_project_fwd_u(const float *agg, const float *x, const float *w_l,
+                                   const float *b_l, const float *w_r, int64_t N, int64_t Fi,
+                                   int64_t Fo, int epilogue, const uint8_t *keep_mask,
+                                   uint64_t seed, float p, float *out, float *rnorm, void *wpack,
+                                   int force_generic, uint64_t *relu_sign, float *u_rows,
+                                   int *u_written, gsage_stream_t stream) {
+  return project_fwd_impl(agg, x, w_l, b_l, w_r, N, Fi, Fo, epilogue, keep_mask, seed, p, out, rnorm,
+                          wpack, force_generic, relu_sign, 0, 0, nullptr, nullptr, stream, u_rows,
+                          u_written);
 }
 
 extern "C" int gsage_project_fwd_blocked_supported(int64_t Fi, int64_t Fo, int in_blocked,

@@ -165,6 +165,9 @@ class GraphSAGE(nn.Module):
         # the input layer leaves its operands behind: the layer after it can recompute the rows it
         # aggregates from them instead of gathering the stored activation (ops.aggregate_hidden1)
         stash = {} if (len(self.convs) > 1 and not self._force_generic and ops.HIDDEN1_RECOMPUTE) else None
+        if stash is not None and ops.hidden1_will_apply(self.in_channels, self.hidden_channels,
+                                                        graph.num_nodes, training):
+            stash["want_u"] = True       # the input layer's kernel writes the gather's rows itself
 
         def agg_for(i):
             if i == 1 and ops.hidden1_applies(stash, self.in_channels, graph.num_nodes):

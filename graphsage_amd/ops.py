@@ -164,9 +164,18 @@ def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int) -> 
     # when the dropout masks of more than 64 columns ride behind them
     if num_nodes * (128 if training and w_l.size(0) > 64 else 64) > (1 << 32):
         return False
-    if training and stash["sign"] is None and stash.get("out") is None:
+    if training and stash.get("u") is None and stash["sign"] is None and stash.get("out") is None:
         return False          # nothing to take the stored activation's zero pattern from
     return bool(_lib.load().gsage_segment_gather_hidden1_supported(w_l.size(0), int(stash["epilogue"])))
+
+
+def hidden1_will_apply(in_channels: int, hidden: int, num_nodes: int, training: bool) -> bool:
+    """The size / shape part of :func:`hidden1_applies`, answerable before the input layer runs."""
+    if not HIDDEN1_RECOMPUTE or in_channels > 7 or num_nodes >= (1 << 26) or hidden not in (64, 128, 256):
+        return False
+    if num_nodes * hidden * 4 < HIDDEN1_MIN_BYTES:
+        return False
+    return num_nodes * (128 if training and hidden > 64 else 64) <= (1 << 32)
 
 
 HIDDEN1_STATS = {"used": 0}      # tests / diagnostics
@@ -174,6 +183,11 @@ HIDDEN1_STATS = {"used": 0}      # tests / diagnostics
 
 def aggregate_hidden1_from(graph: GraphCSR, stash: dict, out_blocked: bool = False) -> torch.Tensor:
     HIDDEN1_STATS["used"] += 1
+    if stash.get("u") is not None:
+        with torch.no_grad():
+            return aggregate_hidden1_u(graph, stash["u"], stash["w_l"].detach().contiguous(),
+                                       stash["b_l"].detach(), stash["w_r"].detach().contiguous(),
+                                       stash["epilogue"], p=stash["p"], out_blocked=out_blocked)
     with torch.no_grad():
         return aggregate_hidden1(graph, stash["agg"], stash["x"], stash["w_l"].detach().contiguous(),
                                  stash["b_l"].detach(), stash["w_r"].detach().contiguous(),
@@ -212,6 +226,28 @@ def aggregate_hidden1(graph: GraphCSR, agg1, x8, w_l, b_l, w_r, epilogue, p: flo
         if ev:
             ev[1].record()
     _lib.check(rc, "gsage_segment_gather_hidden1")
+    return out
+
+
+def aggregate_hidden1_u(graph: GraphCSR, u_rows, w_l, b_l, w_r, epilogue, p: float = 0.0,
+                        out_blocked: bool = False) -> torch.Tensor:
+    """:func:`aggregate_hidden1` on a row table the input layer's kernel already wrote
+    (gsage_segment_gather_hidden1_u): no pack pass."""
+    lib = _lib.load()
+    N, Fo = u_rows.size(0), w_l.size(0)
+    dev = u_rows.device
+    with torch.cuda.device(dev):
+        out = torch.empty((Fo // 64, N, 64) if out_blocked else (N, Fo), dtype=torch.float32, device=dev)
+        ws_bytes = lib.gsage_segment_gather_hidden1_u_workspace_bytes(graph.num_edges, Fo)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _bracket(f"segment_gather_hidden1_F{Fo}"):
+            rc = lib.gsage_segment_gather_hidden1_u(graph.hidden1_groups().data_ptr(), graph.num_edges,
+                                                    graph.col.data_ptr(), graph.inv_deg.data_ptr(),
+                                                    u_rows.data_ptr(), w_l.data_ptr(), b_l.data_ptr(),
+                                                    w_r.data_ptr(), N, Fo, int(epilogue), float(p),
+                                                    out.data_ptr(), int(out_blocked), ws.data_ptr(),
+                                                    ws_bytes, _lib.stream_handle())
+    _lib.check(rc, "gsage_segment_gather_hidden1_u")
     return out
 
 
@@ -293,10 +329,13 @@ def aggregate_mean_bwd(graph: GraphCSR, grad_agg: torch.Tensor, prescaled: bool 
 
 
 def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0, p=0.0,
-                force_generic=False, want_relu_sign: bool = False, alloc_relu_sign: bool = True):
+                force_generic=False, want_relu_sign: bool = False, alloc_relu_sign: bool = True,
+                u_out: Optional[dict] = None):
     """K3 forward -> (out, rnorm).  With ``want_relu_sign`` a third value is returned: the buffer
     of ``out > 0`` bits the first-layer kernel leaves for :func:`project_bwd` (None for shapes
-    and epilogues that have no use for it, or when ``alloc_relu_sign`` is off)."""
+    and epilogues that have no use for it, or when ``alloc_relu_sign`` is off).  ``u_out`` (a
+    dict): asks the first-layer kernel to leave the rows the next layer's recompute gather fetches
+    (gsage_project_fwd_u); ``u_out["u"]`` is the table if the kernel that ran wrote it, else None."""
     lib = _lib.load()
     N, Fi = x.shape
     Fo = w_l.shape[0]
@@ -313,16 +352,29 @@ def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0
         if want_relu_sign and alloc_relu_sign and Fi <= 8 and Fo % 64 == 0 and epilogue in (_lib.EPI_RELU,
                                                                        _lib.EPI_RELU_DROPOUT):
             sign = torch.empty(lib.gsage_relu_sign_bytes(N, Fo) // 8, dtype=torch.int64, device=dev)
-        ev = _timer.bracket(f"project_fwd_{Fi}x{Fo}") if _timer is not None and _timer.enabled else None
-        if ev:
-            ev[0].record()
-        rc = lib.gsage_project_fwd_ex(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), b_l.data_ptr(),
-                                      w_r.data_ptr(), N, Fi, Fo, int(epilogue), _lib.ptr(keep_mask),
-                                      int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), out.data_ptr(),
-                                      _lib.ptr(rnorm), wpack.data_ptr(), int(force_generic),
-                                      _lib.ptr(sign), _lib.stream_handle())
-        if ev:
-            ev[1].record()
+        u_rows, wrote = None, None
+        if u_out is not None and Fi == 8 and Fo in (64, 128, 256) and not force_generic and \
+                epilogue in (_lib.EPI_RELU, _lib.EPI_RELU_DROPOUT):
+            import ctypes
+            u_rows = torch.empty(N, lib.gsage_hidden1_u_row_bytes(Fo, int(epilogue)) // 4,
+                                 dtype=torch.float32, device=dev)
+            wrote = ctypes.c_int(0)
+        with _bracket(f"project_fwd_{Fi}x{Fo}"):
+            if u_rows is not None:
+                rc = lib.gsage_project_fwd_u(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), b_l.data_ptr(),
+                                             w_r.data_ptr(), N, Fi, Fo, int(epilogue), _lib.ptr(keep_mask),
+                                             int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), out.data_ptr(),
+                                             _lib.ptr(rnorm), wpack.data_ptr(), int(force_generic),
+                                             _lib.ptr(sign), u_rows.data_ptr(), ctypes.byref(wrote),
+                                             _lib.stream_handle())
+            else:
+                rc = lib.gsage_project_fwd_ex(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), b_l.data_ptr(),
+                                              w_r.data_ptr(), N, Fi, Fo, int(epilogue), _lib.ptr(keep_mask),
+                                              int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), out.data_ptr(),
+                                              _lib.ptr(rnorm), wpack.data_ptr(), int(force_generic),
+                                              _lib.ptr(sign), _lib.stream_handle())
+        if u_out is not None:
+            u_out["u"] = u_rows if (wrote is not None and wrote.value == 1) else None
     _lib.check(rc, "gsage_project_fwd")
     if want_relu_sign:
         return out, rnorm, sign
@@ -641,15 +693,19 @@ class SAGELayerFunction(torch.autograd.Function):
         # sign bits of the output for the backward, wanted only where the backward stops at this
         # layer's weights (the first layer): then ReLU'/dropout' is applied inside the dW kernel
         want_sign = not (ctx.needs_input_grad[0] or ctx.needs_input_grad[10])
+        # a stash that asks for it ("want_u": the caller will run the next layer's aggregation on the
+        # recompute gather) gets the 64-byte rows written by this layer's own kernel
+        u_box = {} if (stash is not None and stash.get("want_u")) else None
         out, rnorm, sign = project_fwd(agg, x, w_l, b_l, w_r, epilogue, keep_mask, seed, p,
                                        force_generic, want_relu_sign=True,
-                                       alloc_relu_sign=want_sign)
+                                       alloc_relu_sign=want_sign, u_out=u_box)
         ctx.graph, ctx.epilogue, ctx.p, ctx.force_generic = graph, epilogue, p, force_generic
         ctx.save_for_backward(x, agg, out, rnorm, w_l, w_r, sign)
         if stash is not None:
             # what the next layer's aggregation can be recomputed from (aggregate_hidden1)
             stash.update(agg=agg, x=x, w_l=w_l, b_l=b_l, w_r=w_r, sign=sign, epilogue=epilogue, p=p,
-                         out=out if epilogue == _lib.EPI_RELU_DROPOUT else None)
+                         out=out if epilogue == _lib.EPI_RELU_DROPOUT else None,
+                         u=u_box.get("u") if u_box is not None else None)
         return out
 
     @staticmethod

@@ -171,6 +171,17 @@ int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *c
                                  float *out, int out_blocked, void *ws, size_t ws_bytes,
                                  gsage_stream_t stream);
 
+/* The same with the row table handed in: u_rows [N, gsage_hidden1_u_row_bytes(Fo, epilogue) / 4]
+ * as gsage_project_fwd_u left it while it computed the input layer (no pack pass over agg1 / x8 /
+ * the sign bits; the workspace holds only the weight planes and the hub rows' partial sums). */
+size_t gsage_hidden1_u_row_bytes(int64_t Fo, int epilogue);
+size_t gsage_segment_gather_hidden1_u_workspace_bytes(int64_t E, int64_t Fo);
+int gsage_segment_gather_hidden1_u(const void *groups, int64_t E, const int32_t *col,
+                                   const float *inv_deg, const float *u_rows, const float *w_l,
+                                   const float *b_l, const float *w_r, int64_t N, int64_t Fo,
+                                   int epilogue, float p, float *out, int out_blocked, void *ws,
+                                   size_t ws_bytes, gsage_stream_t stream);
+
 /* ------------------------------------------------------------ K3: fused projection
  * Replaces `F.linear(agg, W_l, b_l) + F.linear(x, W_r)` (PyG SAGEConv.forward) fused
  * with F.relu / nn.Dropout (graphsage.py:134-135) or F.normalize (graphsage.py:141-142).
@@ -229,6 +240,19 @@ int gsage_project_fwd_ex(const float *agg, const float *x, const float *w_l,
                          int64_t Fo, int epilogue, const uint8_t *keep_mask,
                          uint64_t seed, float p, float *out, float *rnorm, void *wpack,
                          int force_generic, uint64_t *relu_sign, gsage_stream_t stream);
+/* gsage_project_fwd_ex with a third side channel, forward to the NEXT layer's aggregation:
+ *   u_rows (fwd out, nullable): fp32 [N, gsage_hidden1_u_row_bytes(Fo, epilogue) / 4].  The
+ *             first-layer MFMA kernel (Fi = 8, RELU / RELU_DROPOUT, Fo = 64, 128 or 256) holds
+ *             each row's [agg | x] and, in training, its keep-and-positive ballots: it writes the
+ *             64-byte rows gsage_segment_gather_hidden1_u fetches (graphsage.py:133-135 feeding
+ *             the next SAGEConv's propagate) while it is at it.  *u_written (HOST int, nullable)
+ *             says whether the kernel that was dispatched wrote them (unaligned operands do not
+ *             take that kernel); 0 = use gsage_segment_gather_hidden1, which packs the rows itself. */
+int gsage_project_fwd_u(const float *agg, const float *x, const float *w_l, const float *b_l,
+                        const float *w_r, int64_t N, int64_t Fi, int64_t Fo, int epilogue,
+                        const uint8_t *keep_mask, uint64_t seed, float p, float *out, float *rnorm,
+                        void *wpack, int force_generic, uint64_t *relu_sign, float *u_rows,
+                        int *u_written, gsage_stream_t stream);
 int gsage_project_bwd_ex(const float *grad_out, const float *out, const float *rnorm,
                          const float *agg, const float *x, const float *w_l,
                          const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,

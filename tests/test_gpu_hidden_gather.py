@@ -237,3 +237,34 @@ def test_nan_feature_is_zeroed_by_relu_on_both_aggregation_paths(monkeypatch):
             embs.append(model(x, ei))
     assert torch.isfinite(embs[0]).all() and torch.isfinite(embs[1]).all()
     assert_close(embs[0], embs[1])
+
+
+@pytest.mark.parametrize("n,deg", [(1, 1), (77, 4), (5003, 20), (20000, 40)])
+@pytest.mark.parametrize("fo,train", [(64, False), (64, True), (128, True), (256, True), (256, False)])
+def test_rows_written_by_the_input_layer_kernel_equal_the_packed_ones(n, deg, fo, train):
+    """gsage_project_fwd_u: the first-layer kernel writes the rows u[j] (operands + its own
+    keep-and-positive ballots) while it computes the layer; the gather on that table gives bit for
+    bit what the gather on the table packed afterwards from agg / x / the sign bits gives."""
+    from graphsage_amd import ops
+    p = 0.3
+    ei, x8, wl, b, wr, graph = _setup(n, fo, deg, seed=3 * n + fo)
+    d = [t.cuda() for t in (x8, wl, b, wr)]
+    agg1 = ops.aggregate_mean(graph, d[0])
+    epi = _lib.EPI_RELU_DROPOUT if train else _lib.EPI_RELU
+    box = {}
+    h1, _, sign = ops.project_fwd(agg1, d[0], d[1], d[2], d[3], epilogue=epi, seed=1234 + n, p=p if train else 0.0,
+                                  want_relu_sign=True, u_out=box)
+    assert box["u"] is not None and box["u"].shape == (n, 32 if train and fo > 64 else 16)
+    got = ops.aggregate_hidden1_u(graph, box["u"], d[1], d[2], d[3], epi, p=p if train else 0.0)
+    want = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], epi, p=p if train else 0.0,
+                                 relu_sign=sign if train else None)
+    assert torch.equal(got, want)
+    assert_close(got, ops.aggregate_mean(graph, h1), what="vs the plain gather over the stored rows")
+    # an odd-address keep mask takes another forward kernel: no table, and the box says so
+    if train:
+        buf = torch.empty(n * fo + 1, dtype=torch.uint8, device="cuda")
+        odd = buf[1:].view(n, fo)
+        odd.fill_(1)
+        box2 = {}
+        ops.project_fwd(agg1, d[0], d[1], d[2], d[3], epilogue=epi, keep_mask=odd, p=p, u_out=box2)
+        assert box2["u"] is None
