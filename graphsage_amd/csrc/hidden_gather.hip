@@ -103,11 +103,7 @@ __global__ void __launch_bounds__(256) h1_pack_u_k(const float *__restrict__ agg
   b1[3] = __uint_as_float(hi);
   // rows of 64 bytes; training on more than 64 columns: 128 bytes (still one line per neighbour),
   // the masks of the further column groups behind the row, low words at byte 64, high words at 80
-#ifdef H1_FAKE_PRESPLIT
-  float *u = U + j * 32;
-#else
   float *u = U + j * (train && ngroups > 1 ? 32 : 16);
-#endif
   *(f32x4v *)(u) = a0;
   *(f32x4v *)(u + 4) = a1;
   *(f32x4v *)(u + 8) = b0;
@@ -263,11 +259,7 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
                  const int *__restrict__ hcnt, float *__restrict__ part, int *__restrict__ counter) {
   // bytes per row of the table: training on more than 64 columns carries the further column
   // groups' masks behind the 64-byte row (h1_pack_u_k)
-#ifdef H1_FAKE_PRESPLIT   // TIMING PROBE ONLY (wrong results): a table of three pre-split bf16 planes, 128-byte rows
-  constexpr uint32_t UROW = 128u;
-#else
   constexpr uint32_t UROW = (TRAIN && NB > 2) ? 128u : 64u;
-#endif
   const int lane = gs_lane(), c = lane & 31, h = lane >> 5;
   // The launch is as many waves as the chip holds; they draw their work from one counter: first
   // the pieces of the hub rows (so the long rows overlap everything else), then the chunks of
@@ -287,11 +279,7 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
   // of the upper half) and which bit of it per column block
   const int bp_base = 4 * (((c >> 1) & 1) * 32 + 4 * h);
   const int bit0 = (c & 1) * 16 + (c >> 2);
-#ifdef H1_FAKE_PRESPLIT
-  const uint32_t u_lane = 16u * (uint32_t)h;
-#else
   const uint32_t u_lane = 32u * (uint32_t)h;       // byte offset of this lane's half of a 64-byte row
-#endif
   const int sl = c >> 3, ln = c & 7;               // this lane's slot of a group, its place in the slot
 
   for (;;) {
@@ -343,13 +331,6 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
     DST = -1;                                                                                 \
     if (ln < ((DESC).y & 15)) DST = col[(DESC).x + ln];                                       \
   }
-#ifdef H1_FAKE_PRESPLIT
-#define H1_B_OFF 32
-#define H1_X_OFF 64
-#else
-#define H1_B_OFF 16
-#define H1_X_OFF (64 - 16 * h)
-#endif
 #define H1_LOAD_U(A, B, X, ID)                                                                \
   {                                                                                           \
     A = (f32x4v){0.f, 0.f, 0.f, 0.f};                                                         \
@@ -358,8 +339,8 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
     if ((ID) >= 0) {                                                                          \
       const char *p_ = (const char *)U + ((uint32_t)(ID) * UROW + u_lane);                    \
       A = *(const f32x4v *)p_;                                                                \
-      B = *(const f32x4v *)(p_ + H1_B_OFF);                                                   \
-      if (UROW > 64u) X = *(const u32x4v *)(p_ + H1_X_OFF);   /* byte 64 + 16 h of the row */ \
+      B = *(const f32x4v *)(p_ + 16);                                                         \
+      if (UROW > 64u) X = *(const u32x4v *)(p_ + (64 - 16 * h));   /* byte 64 + 16 h of the row */ \
     }                                                                                         \
   }
     int2 d0, d1, d2, d3;          // descriptors of group g, g + 1, g + 2, g + 3 (this lane's slot)
@@ -392,11 +373,6 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
 #pragma unroll
         for (int g_ = 1; g_ < NB / 2; ++g_) mword[g_] = ux[g_ - 1];     // zero without a neighbour
       }
-#ifdef H1_FAKE_PRESPLIT
-      if (TRAIN) mword[0] = live ? ux[3] : 0u;
-      const bf16x8 a1 = __builtin_bit_cast(bf16x8, ua), a2 = __builtin_bit_cast(bf16x8, ub),
-                   a3 = __builtin_bit_cast(bf16x8, ux);
-#else
       ub[3] = (live && h == 0) ? 1.f : 0.f;          // k = 7: the bias column; k = 15: nothing
       uint32_t p1[8], p2[8], p3[8];
 #pragma unroll
@@ -415,7 +391,6 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
 #undef H1_PK
       const bf16x8 a1 = __builtin_bit_cast(bf16x8, w1), a2 = __builtin_bit_cast(bf16x8, w2),
                    a3 = __builtin_bit_cast(bf16x8, w3);
-#endif
       // 64 columns (two blocks) at a time, so that the accumulators and slot sums of a wide layer
       // never live together
 #pragma unroll
@@ -550,9 +525,6 @@ extern "C" int gsage_segment_gather_hidden1_supported(int64_t Fo, int epilogue) 
 
 // bytes per row of the table u[j]: 64, or 128 when the masks of more than 64 columns ride along
 static inline size_t h1_urow_bytes(int64_t Fo, int epilogue) {
-#ifdef H1_FAKE_PRESPLIT
-  return 128;
-#endif
   return epilogue == GSAGE_EPI_RELU_DROPOUT && Fo > 64 ? 128 : 64;
 }
 
