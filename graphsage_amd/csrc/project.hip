@@ -1341,18 +1341,13 @@ proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
   const int64_t ntiles = (M + 63) / 64;
   // operands of tile i+1 are fetched into registers underneath tile i's MFMAs and epilogue
   float4 r1[4], r2[4];
-#ifdef P64_FAKE_U   // TIMING PROBE ONLY (wrong results): the root operand fetched from 64-byte rows
-#define P64_XOFF(ROW, C4) ((ROW) * 16 + ((C4) & 12))
-#else
-#define P64_XOFF(ROW, C4) ((ROW) * 64 + (C4))
-#endif
 #define S64_FETCH(ROW0)                                                     \
   _Pragma("unroll") for (int p = 0; p < 4; ++p) {                           \
     int64_t row = (ROW0) + p * 16 + rsub;                                   \
     bool in = row < M;                                                      \
     row = in ? row : 0;                                                     \
     r1[p] = *(const float4 *)(agg + row * 64 + c4);                         \
-    r2[p] = *(const float4 *)(x + P64_XOFF(row, c4));                       \
+    r2[p] = *(const float4 *)(x + row * 64 + c4);                           \
     if (!in) { r1[p] = make_float4(0.f, 0.f, 0.f, 0.f); r2[p] = r1[p]; }    \
   }
   if ((int64_t)blockIdx.x < ntiles) { S64_FETCH((int64_t)blockIdx.x * 64) }
