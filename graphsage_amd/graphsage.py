@@ -166,11 +166,11 @@ class GraphSAGE(nn.Module):
         # aggregates from them instead of gathering the stored activation (ops.aggregate_hidden1)
         stash = {} if (len(self.convs) > 1 and not self._force_generic and ops.HIDDEN1_RECOMPUTE) else None
         if stash is not None and ops.hidden1_will_apply(self.in_channels, self.hidden_channels,
-                                                        graph.num_nodes, training):
+                                                        graph.num_nodes, training, graph.num_edges):
             stash["want_u"] = True       # the input layer's kernel writes the gather's rows itself
 
         def agg_for(i):
-            if i == 1 and ops.hidden1_applies(stash, self.in_channels, graph.num_nodes):
+            if i == 1 and ops.hidden1_applies(stash, self.in_channels, graph.num_nodes, graph.num_edges):
                 return ops.aggregate_hidden1_from(graph, stash)
             return None
 
@@ -229,7 +229,7 @@ class GraphSAGE(nn.Module):
         # the activation's F/64 rows of 256 bytes)
         stash = dict(agg=agg1, x=x8, w_l=w_l, b_l=first.lin_l.bias, w_r=w_r, sign=None,
                      epilogue=_lib.EPI_RELU, p=0.0)
-        recompute = ops.hidden1_applies(stash, first.in_channels, graph.num_nodes)
+        recompute = ops.hidden1_applies(stash, first.in_channels, graph.num_nodes, graph.num_edges)
 
         def aggregate(i, h):
             if i == 0 and recompute:

@@ -143,13 +143,18 @@ def aggregate_mean(graph: GraphCSR, x: torch.Tensor) -> torch.Tensor:
 # (gsage_segment_gather_hidden1).  GSAGE_HIDDEN1_RECOMPUTE=0 keeps the plain gather.
 HIDDEN1_RECOMPUTE = os.environ.get("GSAGE_HIDDEN1_RECOMPUTE", "1") != "0"
 # ... from the size on where it wins: below it the plain gather reads the stored activation out of
-# the caches.  Measured on the benchmark graphs (tools/hidden_gather_probe.py, pack kernels
-# included): break-even at 400 k nodes x 64 columns (eval and training alike), 150 k x 128, 100 k x
-# 256, i.e. 75 - 100 MB of activation whatever the width.
-HIDDEN1_MIN_BYTES = int(os.environ.get("GSAGE_HIDDEN1_MIN_BYTES", str(96 << 20)))
+# the caches.  What decides is the bytes the plain gather would fetch, E x 4 Fo: measured break-even
+# (tools/hidden_gather_probe.py, tools/hidden_gather_shapes_probe.py; pack kernels included) at
+# 400 k nodes x 64 columns, 150 k x 128, 100 k x 256 on the benchmark's degree distribution (mean
+# 20), and for 64 columns at ~1.5 M nodes with mean degree 5, ~130 k with mean degree 60 -- 1.5 to
+# 2.05 GB of gathered rows every time, whatever the tail exponent (2.1 / 2.5 / 3.5, or degrees
+# capped at 40).  Round 2 switched on the size of the activation (96 MiB), which is the same
+# thing at mean degree 20 only.
+HIDDEN1_MIN_BYTES = int(os.environ.get("GSAGE_HIDDEN1_MIN_BYTES", str(7 << 28)))     # 1.75 GiB
 
 
-def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int) -> bool:
+def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int,
+                    num_edges: Optional[int] = None) -> bool:
     """Can the aggregation of the layer whose forward filled ``stash`` be recomputed?  Its input
     must be the 7 (or fewer) features padded to 8 columns and its epilogue one the kernel has."""
     if not HIDDEN1_RECOMPUTE or not stash or in_channels > 7 or num_nodes >= (1 << 26):
@@ -158,7 +163,8 @@ def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int) -> 
     if x.size(1) != 8 or w_l.size(1) != 8 or not x.is_cuda:
         return False
     training = stash["epilogue"] == _lib.EPI_RELU_DROPOUT
-    if num_nodes * w_l.size(0) * 4 < HIDDEN1_MIN_BYTES:
+    edges = num_edges if num_edges is not None else 20 * num_nodes
+    if edges * w_l.size(0) * 4 < HIDDEN1_MIN_BYTES:
         return False
     # the kernel addresses its row table with 32-bit byte offsets: 64-byte rows, or 128-byte rows
     # when the dropout masks of more than 64 columns ride behind them
@@ -169,11 +175,13 @@ def hidden1_applies(stash: Optional[dict], in_channels: int, num_nodes: int) -> 
     return bool(_lib.load().gsage_segment_gather_hidden1_supported(w_l.size(0), int(stash["epilogue"])))
 
 
-def hidden1_will_apply(in_channels: int, hidden: int, num_nodes: int, training: bool) -> bool:
+def hidden1_will_apply(in_channels: int, hidden: int, num_nodes: int, training: bool,
+                       num_edges: Optional[int] = None) -> bool:
     """The size / shape part of :func:`hidden1_applies`, answerable before the input layer runs."""
     if not HIDDEN1_RECOMPUTE or in_channels > 7 or num_nodes >= (1 << 26) or hidden not in (64, 128, 256):
         return False
-    if num_nodes * hidden * 4 < HIDDEN1_MIN_BYTES:
+    edges = num_edges if num_edges is not None else 20 * num_nodes
+    if edges * hidden * 4 < HIDDEN1_MIN_BYTES:
         return False
     return num_nodes * (128 if training and hidden > 64 else 64) <= (1 << 32)
 

@@ -87,6 +87,7 @@ class TrainStep:
                                           weight_decay=weight_decay, capturable=on_gpu,
                                           foreach=False if not on_gpu else None)
         self._graph = None
+        self._graph_tail = None          # (data-parallel capture: clip + Adam behind the all-reduce)
         self._held: list = []            # what a captured graph's addresses point into
         self._captured_versions = None
         # opt-in (graphsage_amd/receptive.py): compute only the 2-hop closure of the batch
@@ -171,15 +172,16 @@ class TrainStep:
     def capture_step(self, batch_size: int, num_negatives: int, warmup: int = 3,
                      preserve_state: bool = False) -> None:
         """Capture zero_grad -> forward -> loss -> backward -> clip -> Adam into ONE HIP graph
-        for batches of exactly (batch_size, num_negatives).  Worth it when the graph is small
-        and the step is launch-bound (the reference's default B = 1024 on its 500-node graph:
-        ~60 launches of a few microseconds each).  Dropout masks are then drawn by torch's
-        graph-safe Philox generator and handed to the projection kernel as keep-masks (a seed
-        passed by value would be frozen into the graph).  The warm-up and the capture run real
-        steps on an all-zero batch; ``preserve_state`` puts parameters and Adam state back as
-        they were afterwards (what a trainer wants when it captures in the middle of a run)."""
-        if self.world > 1:
-            raise RuntimeError("capture_step covers the single-GPU step only")
+        for batches of exactly (batch_size, num_negatives) -- per rank, when a process group is
+        in use: the step is then TWO graphs, [zero_grad .. backward] and [clip, Adam], with the one
+        all-reduce of the flat buffer issued between their replays.  Worth it when the graph is
+        small and the step is launch-bound (the reference's default B = 1024 on its 500-node
+        graph: ~60 launches of a few microseconds each).  Dropout masks are then drawn by a
+        graph-safe Philox generator of the stepper's own, seeded with the base seed every replica
+        shares, and handed to the projection kernel as keep-masks (a seed passed by value would
+        be frozen into the graph).  The warm-up and the capture run real steps on an all-zero
+        batch; ``preserve_state`` puts parameters and Adam state back as they were afterwards
+        (what a trainer wants when it captures in the middle of a run)."""
         dev = self.features.device
         saved = None
         if preserve_state:
@@ -189,17 +191,36 @@ class TrainStep:
         self._gt = torch.zeros(batch_size, dtype=torch.int64, device=dev)
         self._gc = torch.zeros(batch_size, dtype=torch.int64, device=dev)
         self._gn = torch.zeros(batch_size, num_negatives, dtype=torch.int64, device=dev)
+        # masks: the same stream on every replica (same seed, same number of draws: warm-up,
+        # capture and replays run in lockstep by construction), untouched by whatever else the
+        # process draws from torch's default generators
+        self._mask_gen = torch.Generator(device=dev)
+        self._mask_gen.manual_seed(self.base_seed & 0x7FFFFFFFFFFFFFFF)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(warmup):          # builds the CSR cache, sets kernel attributes
-                self._graph_body(batch_size)
+                self._graph_front(batch_size)
+                if self.world > 1:
+                    self._all_reduce_flat()
+                self._graph_back()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         # the warm-up steps above moved the parameters: that is the caller's to know
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._graph_body(batch_size)
+        self._graph.register_generator_state(self._mask_gen)
+        self._graph_tail = None
+        if self.world == 1:
+            with torch.cuda.graph(self._graph):
+                self._graph_front(batch_size)
+                self._graph_back()
+        else:
+            with torch.cuda.graph(self._graph):
+                self._graph_front(batch_size)
+            self._all_reduce_flat()          # (keeps the ranks' collectives paired up)
+            self._graph_tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_tail, pool=self._graph.pool()):
+                self._graph_back()
         # The captured kernels hold raw device addresses of tensors that only the process-wide
         # GraphCache owns (the CSR built during warm-up, the 7 -> 8 padded features, a cached
         # input aggregate).  Keep them alive here for as long as the graph exists, whatever the
@@ -215,7 +236,8 @@ class TrainStep:
                     if torch.is_tensor(v):      # in place: the graph holds these addresses
                         v.copy_(saved[1][k]) if k in saved[1] else v.zero_()
 
-    def _graph_body(self, batch_size: int) -> None:
+    def _graph_front(self, batch_size: int) -> None:
+        """zero_grad -> forward -> loss on this rank's (static) batch -> backward -> stats."""
         model = self.model
         model.train()
         self.flat.zero_grad()
@@ -223,14 +245,18 @@ class TrainStep:
         p = float(getattr(model, "dropout_rate", 0.0))
         if p > 0.0:
             n = self.features.size(0)
-            masks = [(torch.rand(n, conv.out_channels, device=self.features.device) >= p)
-                     .to(torch.uint8) for conv in model.convs[:-1]]
+            masks = [(torch.rand(n, conv.out_channels, device=self.features.device,
+                                 generator=self._mask_gen) >= p).to(torch.uint8)
+                     for conv in model.convs[:-1]]
         emb = model(self.features, self.edge_index, keep_masks=masks)
         loss, stats = self.loss_fn.forward_stats(emb, self._gt, self._gc, self._gn,
-                                                 global_batch=batch_size)
+                                                 global_batch=batch_size * self.world)
         loss.backward()
         self._release_grad_table()
         self.flat.extra.copy_(stats)
+
+    def _graph_back(self) -> None:
+        """clip -> Adam on the (all-reduced) flat gradient."""
         if self.gradient_clip > 0:
             torch.nn.utils.clip_grad_norm_([self.flat.flat_param], self.gradient_clip)
         self.optimizer.step()
@@ -247,13 +273,16 @@ class TrainStep:
         if (self.features._version, self.edge_index._version) != self._captured_versions:
             # an in-place change of the graph or the features: the captured kernels would go on
             # reading the CSR / padded copy made from the old contents
-            self._graph, self._held = None, []
+            self._graph, self._graph_tail, self._held = None, None, []
             raise RuntimeError("features or edge_index were modified in place after capture_step(); "
                                "capture again")
         self._gt.copy_(targets)
         self._gc.copy_(contexts)
         self._gn.copy_(negatives)
         self._graph.replay()
+        if self._graph_tail is not None:
+            self._all_reduce_flat()
+            self._graph_tail.replay()
         return self.flat.extra
 
     # ----------------------------------------------- optimiser state in the reference's layout

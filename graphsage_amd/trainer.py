@@ -175,7 +175,7 @@ class GraphSAGETrainer:
         # large or the step is long enough to hide its launches
         hg = tc.get("hip_graph", "auto")
         self._use_graph = (hg is True or (hg == "auto" and features.size(0) <= 200_000)) and \
-            self.stepper.world == 1 and len(self.batch_generator) > 1 and \
+            len(self.batch_generator) > 1 and \
             self.train_pairs[0].numel() >= self.batch_size and not self.stepper.receptive_field
         self._graph_ready = False
         # the reference builds its stopping rule once (trainer.py:166): patience counter and best

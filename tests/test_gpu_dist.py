@@ -29,3 +29,8 @@ def test_two_ranks_on_one_gpu_match_single_process():
         assert a == pytest.approx(b, rel=1e-5)
     assert d["max_param_diff"] <= 1e-5
     assert d["live_rows_used"] == 6          # 3 sharded steps + 3 whole-batch steps on rank 0
+    # the captured form (two HIP graphs per rank around the all-reduce, masks from the stepper's
+    # own graph-safe generator seeded with the shared base seed) against one captured process
+    for a, b in zip(d["captured_losses"], d["captured_ref_losses"]):
+        assert a == pytest.approx(b, rel=1e-5)
+    assert d["captured_max_param_diff"] <= 1e-5

@@ -52,10 +52,28 @@ def main():
         worst = max(float((a.detach() - b.detach()).abs().max())
                     for a, b in zip(model.parameters(), ref_model.parameters()))
         from graphsage_amd import ops
-        print(json.dumps({"world": world, "losses": losses, "ref_losses": ref_losses,
-                          "max_param_diff": worst, "live_rows_used": ops.LIVE_STATS["used"],
-                          "dropout": DROPOUT}),
-              flush=True)
+        result = {"world": world, "losses": losses, "ref_losses": ref_losses,
+                  "max_param_diff": worst, "live_rows_used": ops.LIVE_STATS["used"],
+                  "dropout": DROPOUT}
+    # ---- the same with the step captured: per rank two HIP graphs around the one all-reduce
+    Bc = 4096                                             # even shards: the graphs fix the batch size
+    cbatches = [cooccurrence_batch(ei, n, Bc, K, seed=30 + s) for s in range(steps)]
+    cmodel = GraphSAGE(7, 64, 64, 2, DROPOUT).to(dev)
+    cmodel.load_state_dict(init)
+    cts = TrainStep(cmodel, x, ei, seed=4242)
+    lo, hi = shard_bounds(Bc, rank, world)
+    cts.capture_step(hi - lo, K, preserve_state=True)
+    closses = [float(cts.step_captured(t[lo:hi], c[lo:hi], neg[lo:hi])[0]) for t, c, neg in cbatches]
+    if rank == 0:
+        rmodel = GraphSAGE(7, 64, 64, 2, DROPOUT).to(dev)
+        rmodel.load_state_dict(init)
+        rts = TrainStep(rmodel, x, ei, seed=4242, distributed=False)
+        rts.capture_step(Bc, K, preserve_state=True)
+        rlosses = [float(rts.step_captured(*b)[0]) for b in cbatches]
+        result.update({"captured_losses": closses, "captured_ref_losses": rlosses,
+                       "captured_max_param_diff": max(float((a.detach() - b.detach()).abs().max())
+                                                      for a, b in zip(cmodel.parameters(), rmodel.parameters()))})
+        print(json.dumps(result), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
