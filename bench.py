@@ -415,10 +415,11 @@ def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
                          (2 + K) * (4 * D + 8) * B),
         "skipgram_bwd_atomic": (["skipgram_bwd_k"], "skip-gram loss backward (float atomics)",
                                 3 * (2 + K) * 4 * D * B),
-        "skipgram_bwd_det": (["seg_gather_vec_k<16, 2, false>", "radix_scatter_k", "radix_hist_k"],
+        "skipgram_bwd_det": ([f"seg_gather_vec_k<{D // 4}, 2, false>", "radix_scatter_k<true>*3", "sg_terms_k"],
                              "skip-gram loss backward (sorted, deterministic)", 3 * (2 + K) * 4 * D * B),
-        "skipgram_bwd_rows": (["sg_rows_gather_k<16>", "radix_scatter_k<true>", "radix_hist_k", "sg_terms_rows_k",
-                               "rowptr_from_sorted_k"],
+        "skipgram_bwd_rows": (["sg_rows_gather_k<16>", "radix_scatter_k<true>*3", "sg_terms_rows_k"],
+                              # (radix_hist_k and rowptr_from_sorted_k also run in the CSR build, on 200 M
+                              # keys: their per-launch means in the counter file are not this call's)
                               "skip-gram loss backward: terms sorted by place in the touched-row list, "
                               "summed row by row (deterministic, no atomics)",
                               # terms listed (ids read, 12 B written), three radix passes over (row, source,
@@ -436,7 +437,12 @@ def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
         kernels, what, useful = models.get(tag, ([], tag, None))
         traffic, src, stale = None, None, None
         if not args.nodes and kernels:
-            parts = [measured_traffic(args.workload, k) for k in kernels]
+            # "name*3": that kernel runs three times per call (the file holds means per launch)
+            parts = []
+            for k in kernels:
+                kname, _, times = k.partition("*")
+                t_, src_, stale_ = measured_traffic(args.workload, kname)
+                parts.append((t_ * int(times or 1) if t_ is not None else None, src_, stale_))
             got = [p for p in parts if p[0] is not None]
             if got and parts[0][0] is not None:          # the main kernel must be in the file
                 traffic = sum(p[0] for p in got)

@@ -264,8 +264,7 @@ __global__ void __launch_bounds__(256)
 sg_terms_k(const int64_t *__restrict__ tg, const int64_t *__restrict__ ctx,
            const int64_t *__restrict__ neg, int64_t B, int64_t K, int64_t N,
            const float *__restrict__ coef, const float *__restrict__ grad_loss,
-           int *__restrict__ key, int *__restrict__ val, int *__restrict__ tsrc,
-           float *__restrict__ tw) {
+           int *__restrict__ key, int *__restrict__ tsrc, float *__restrict__ tw) {
   const int64_t M = B * 2 * (1 + K);
   const float g = *grad_loss;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -278,28 +277,16 @@ sg_terms_k(const int64_t *__restrict__ tg, const int64_t *__restrict__ ctx,
     bool bad = (uint64_t)dst >= (uint64_t)N || (uint64_t)src >= (uint64_t)N;
     int k = bad ? (int)N : (int)dst;          // sentinel row N: sorted last, never read
     key[e] = k;
-    val[e] = (int)e;
-    // source row and weight of the term, in term order: after the sort they are fetched through
-    // the permutation (two 4-byte reads) instead of being re-derived from the pair arrays
+    // source row and weight of the term travel through the (stable) sort as its two payloads: no
+    // permutation to apply afterwards, and equal rows keep their terms in term order
     tsrc[e] = bad ? 0 : (int)src;
     tw[e] = bad ? 0.f : coef[b * (1 + K) + r] * g;
   }
 }
 
-__global__ void __launch_bounds__(256)
-sg_materialise_k(const int *__restrict__ perm, int64_t M, const int *__restrict__ tsrc,
-                 const float *__restrict__ tw, int *__restrict__ col, float *__restrict__ w) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < M; p += stride) {
-    const int e = perm[p];
-    col[p] = tsrc[e];
-    w[p] = tw[e];
-  }
-}
-
 struct DetLayout {
-  size_t total, o_key, o_val, o_kA, o_vA, o_kB, o_vB, o_counts, o_bsum, o_rowptr, o_col,
-      o_w, o_tsrc, o_tw, o_long, o_nlong;
+  size_t total, o_key, o_src, o_tw, o_kA, o_vA, o_wA, o_kB, o_vB, o_wB, o_counts, o_bsum, o_rowptr,
+      o_col, o_w, o_long, o_nlong;
   int64_t M, long_cap;
 };
 
@@ -317,15 +304,14 @@ DetLayout det_layout(int64_t N, int64_t B, int64_t K) {
   int64_t ncounts = 256 * (ntiles > 0 ? ntiles : 1);
   int64_t scan_n = ncounts > (N + 2) ? ncounts : (N + 2);
   L.long_cap = L.M / gsage_long_row_threshold() + 1;
-  L.o_key = take(m4); L.o_val = take(m4);
-  L.o_kA = take(m4); L.o_vA = take(m4); L.o_kB = take(m4); L.o_vB = take(m4);
+  L.o_key = take(m4); L.o_src = take(m4); L.o_tw = take(m4);
+  L.o_kA = take(m4); L.o_vA = take(m4); L.o_wA = take(m4);
+  L.o_kB = take(m4); L.o_vB = take(m4); L.o_wB = take(m4);
   L.o_counts = take((size_t)ncounts * 4);
   L.o_bsum = take((size_t)((scan_n + GS_SCAN_CH - 1) / GS_SCAN_CH + 1) * 4);
   L.o_rowptr = take((size_t)(N + 2) * 4);
   L.o_col = take(m4);
   L.o_w = take(m4);
-  L.o_tsrc = take(m4);
-  L.o_tw = take(m4);
   L.o_long = take((size_t)L.long_cap * 4);
   L.o_nlong = take(16);
   L.total = off;
@@ -801,7 +787,8 @@ extern "C" int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D,
   if (ws_bytes < L.total) return GSAGE_ERR_WORKSPACE;
   hipStream_t st = gs_stream(stream);
   char *b = (char *)ws;
-  int *key = (int *)(b + L.o_key), *val = (int *)(b + L.o_val);
+  int *key = (int *)(b + L.o_key), *tsrc = (int *)(b + L.o_src);
+  float *tw = (float *)(b + L.o_tw);
   GsSortWs sw{(int *)(b + L.o_kA), (int *)(b + L.o_vA), (int *)(b + L.o_kB), (int *)(b + L.o_vB),
               (int *)(b + L.o_counts), (int *)(b + L.o_bsum)};
   int *rowptr = (int *)(b + L.o_rowptr);
@@ -810,26 +797,17 @@ extern "C" int gsage_skipgram_bwd_det(const float *emb, int64_t N, int64_t D,
   int *longs = (int *)(b + L.o_long), *nlong = (int *)(b + L.o_nlong);
 
   if (!gs_zero_async(nlong, 16, st)) return GSAGE_ERR_LAUNCH;
-  int *tsrc = (int *)(b + L.o_tsrc);
-  float *tw = (float *)(b + L.o_tw);
   hipLaunchKernelGGL(sg_terms_k, dim3(gs_grid(L.M, 256, 1 << 16)), dim3(256), 0, st, targets,
-                     contexts, negatives, B, K, N, coef, grad_loss, key, val, tsrc, tw);
+                     contexts, negatives, B, K, N, coef, grad_loss, key, tsrc, tw);
   GSAGE_CHECK_LAUNCH();
   int bits = 0;
   while ((1ll << bits) <= N) ++bits;
-  int *perm = key;   // the keys are dead after the sort's first pass has read them: reuse
-  // (the first pass reads `key` and writes kA/vA; the last pass writes `perm`; with a single
-  //  pass it would read and write the same array, so that case sorts into vB instead)
-  int passes = (bits + 7) / 8;
-  if (passes == 1) perm = sw.vB;
   const int *skey = nullptr;
-  int rc = gs_radix_sort_vals(key, val, L.M, bits, perm, sw, st, &skey);
+  int rc = gs_radix_sort_vals2(key, tsrc, (const int *)tw, L.M, bits, col, (int *)w, sw,
+                               (int *)(b + L.o_wA), (int *)(b + L.o_wB), st, &skey);
   if (rc) return rc;
   rc = gs_rowptr_from_sorted(skey, L.M, N, rowptr, st);   // row boundaries off the sorted keys
   if (rc) return rc;
-  hipLaunchKernelGGL(sg_materialise_k, dim3(gs_grid(L.M, 256, 1 << 16)), dim3(256), 0, st, perm,
-                     L.M, tsrc, tw, col, w);
-  GSAGE_CHECK_LAUNCH();
   rc = gs_list_long_rows(rowptr, N, longs, L.long_cap, nlong, st);
   if (rc) return rc;
   return gsage_segment_gather_ew(rowptr, col, w, emb, N, D, grad_emb, longs, nlong, stream);
