@@ -42,6 +42,7 @@ SIGNATURES = {
     "gsage_segment_gather_hidden1": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int,
                                                C.c_float, _p, _p, _p, C.c_int, _p, _sz, _p]),
     "gsage_hidden1_u_row_bytes": (_sz, [_i64, C.c_int]),
+    "gsage_hidden1_u_rows": (_i64, [_i64]),
     "gsage_segment_gather_hidden1_u_workspace_bytes": (_sz, [_i64, _i64]),
     "gsage_segment_gather_hidden1_u": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int,
                                                  C.c_float, _p, C.c_int, _p, _sz, _p]),

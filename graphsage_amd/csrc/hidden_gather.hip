@@ -13,10 +13,17 @@
 // A wave takes chunks of 64 destination rows (drawn from a work counter: the launch is as many waves
 // as the chip holds); their neighbours are walked in groups of 32 (four slots of 8, see the group
 // index below): the 32 rows u[j] are the A operand of
-// v_mfma_f32_32x32x16_bf16 (K = 16 is exactly the layer's input width, the bias rides in the
-// padding column 7), every fp32 operand as the exact sum of three bf16 parts and the six largest
-// of the nine products issued, smallest first (project.hip, gemm_split_k: fp32-equivalent
-// accuracy).  The accumulator comes out as D[neighbour][column] with the neighbours in the
+// v_mfma_f32_32x32x16_f16 (K = 16 is exactly the layer's input width, the bias rides in the
+// padding column 7), every fp32 operand as the sum of TWO fp16 parts (22 bits of significand) and
+// three of the four products issued, smallest first (project.hip, gemm_half_k: max error 4e-7 of
+// the largest output, against 3e-7 for the three-way bf16 split used until round 3, at half the
+// matrix instructions).  fp16 has the significand but not the range, so both operands are scaled
+// by exact powers of two: the rows by 2^13 / A', A' = the power of two at or below max |u| over
+// the whole table (which the kernel that writes the table publishes behind it), the weights by
+// 2^13 over their own largest magnitude (h1_pack_w_k), undone by one factor at the row store.
+// Absolute error of an operand <= max(2^-21 |v|, 2^-38 max|v|): results are accurate relative to
+// the largest terms of a pre-activation, whatever the scale of the features.
+// The accumulator comes out as D[neighbour][column] with the neighbours in the
 // registers of a lane, so the activation and the sum over the neighbours are in-lane work
 // and only the two lane halves are combined once per destination row.
 //   eval  (RELU):         act = max(., 0)
@@ -29,7 +36,9 @@
 
 namespace {
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));      // (a B operand as stored: 8 halves)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
@@ -43,22 +52,46 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 constexpr int H1_WG_WAVES = H1_WG_WAVES_;   // waves per workgroup of the gather kernel (they share nothing)
 constexpr int H1_ROWS = H1_ROWS_PER_WAVE;   // destination rows per wave, at most 64 (one trip per wave, in-order dispatch)
 
-// ---- weight planes: Wc[n][k] = k < 7 ? W_l[n][k] : k == 7 ? b[n] : k < 15 ? W_r[n][k-8] : 0,
-// split into three bf16 planes [3][Fo][16]
+// ---- weight planes.  With A' = the power of two at or below max |u| (1 if that is 0, Inf or NaN):
+//   W'[n][k] = k < 7 ? W_l[n][k] A' : k == 7 ? b[n] : k < 15 ? W_r[n][k-8] A' : 0,
+// so that (u / A') . W' with a 1 in slot 7 is the pre-activation; then W' s_w, s_w = the power of
+// two that takes max |W'| into [2^13, 2^14), split into two fp16 planes [2][Fo][16].
+// params[0] = 2^13 / A' (the rows' scale), params[1] = 2^-13 / s_w (undoes both).  One workgroup.
+constexpr float H1_TOP = 8192.f;      // 2^13: where the largest operand magnitudes are put
+__device__ __forceinline__ float h1_pow2_floor(float v, float fallback) {
+  // 2^floor(log2 v) for a normal positive v within 2^+-100, else `fallback`
+  const uint32_t e = (__float_as_uint(v) >> 23) & 255u;
+  if (!(v > 0.f) || e < 27u || e > 227u) return fallback;
+  return __uint_as_float(e << 23);
+}
 __global__ void __launch_bounds__(256) h1_pack_w_k(const float *__restrict__ wl, const float *__restrict__ bl,
                                                    const float *__restrict__ wr, int Fo,
-                                                   uint16_t *__restrict__ planes) {
+                                                   const uint32_t *__restrict__ u_amax,
+                                                   uint16_t *__restrict__ planes, float *__restrict__ params) {
+  __shared__ float red[4];
   const int total = Fo * 16;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+  const float Ap = h1_pow2_floor(__uint_as_float(*u_amax), 1.f);
+  auto value = [&](int e) {
     const int n = e >> 4, k = e & 15;
-    const float v = k < 7 ? wl[n * 8 + k] : k == 7 ? bl[n] : k < 15 ? wr[n * 8 + (k - 8)] : 0.f;
-    const uint32_t u1 = __float_as_uint(v) & 0xFFFF0000u;
-    const float r1 = v - __uint_as_float(u1);
-    const uint32_t u2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(u2);
-    planes[e] = (uint16_t)(u1 >> 16);
-    planes[total + e] = (uint16_t)(u2 >> 16);
-    planes[2 * total + e] = (uint16_t)(__float_as_uint(r2) >> 16);
+    return k < 7 ? wl[n * 8 + k] * Ap : k == 7 ? bl[n] : k < 15 ? wr[n * 8 + (k - 8)] * Ap : 0.f;
+  };
+  float m = 0.f;
+  for (int e = threadIdx.x; e < total; e += 256) m = fmaxf(m, fabsf(value(e)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sw = H1_TOP / h1_pow2_floor(m, H1_TOP);          // (no usable maximum: scale 1)
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const float v = value(e) * sw;
+    const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+    planes[e] = __builtin_bit_cast(uint16_t, hi);
+    planes[total + e] = __builtin_bit_cast(uint16_t, lo);
+  }
+  if (threadIdx.x == 0) {
+    params[0] = H1_TOP / Ap;
+    params[1] = 1.f / (H1_TOP * sw);
   }
 }
 
@@ -71,14 +104,29 @@ __global__ void __launch_bounds__(256) h1_pack_w_k(const float *__restrict__ wl,
 __global__ void __launch_bounds__(256) h1_pack_u_k(const float *__restrict__ agg1, const float *__restrict__ x8,
                                                    int64_t N, int train, int ngroups, const float *__restrict__ h1,
                                                    const unsigned long long *__restrict__ sign,
-                                                   float *__restrict__ U) {
+                                                   float *__restrict__ U, uint32_t *__restrict__ u_amax) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   // the flag word behind the bits says whether the forward kernel that ran wrote them
   const int64_t ngrp4 = (N + 3) >> 2;
   const bool have_bits = train && sign && sign[ngrp4 * 4 * ngroups] != 0ull;
+  f32x4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+  if (j < N) {
+    a0 = *(const f32x4v *)(agg1 + j * 8); a1 = *(const f32x4v *)(agg1 + j * 8 + 4);
+    b0 = *(const f32x4v *)(x8 + j * 8); b1 = *(const f32x4v *)(x8 + j * 8 + 4);
+  }
+  {
+    // max |u| over the table, for the gather's fp16 scaling (float bits of |v| compare as integers)
+    uint32_t mx = 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mx = max(mx, __float_as_uint(a0[e]) & 0x7FFFFFFFu); mx = max(mx, __float_as_uint(b0[e]) & 0x7FFFFFFFu);
+      if (e < 3) { mx = max(mx, __float_as_uint(a1[e]) & 0x7FFFFFFFu); mx = max(mx, __float_as_uint(b1[e]) & 0x7FFFFFFFu); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > __atomic_load_n(u_amax, __ATOMIC_RELAXED)) atomicMax(u_amax, mx);
+  }
   if (j >= N) return;
-  f32x4v a0 = *(const f32x4v *)(agg1 + j * 8), a1 = *(const f32x4v *)(agg1 + j * 8 + 4);
-  f32x4v b0 = *(const f32x4v *)(x8 + j * 8), b1 = *(const f32x4v *)(x8 + j * 8 + 4);
   // the mask of columns 64 g .. 64 g + 63 (group g), as two words
   auto mask_of = [&](int g, uint32_t &lo, uint32_t &hi) {
     lo = 0u; hi = 0u;
@@ -254,7 +302,8 @@ template <int NB, bool TRAIN>
 __global__ void __launch_bounds__(64 * H1_WG_WAVES)
 hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
                  const int *__restrict__ col, const float *__restrict__ inv_deg,
-                 const float *__restrict__ U, const uint16_t *__restrict__ Wp, int64_t N, float scale,
+                 const float *__restrict__ U, const uint16_t *__restrict__ Wp,
+                 const float *__restrict__ params, int64_t N, float scale,
                  float *__restrict__ out, int64_t out_blk, const int2 *__restrict__ pieces,
                  const int *__restrict__ hcnt, float *__restrict__ part, int *__restrict__ counter) {
   // bytes per row of the table: training on more than 64 columns carries the further column
@@ -267,13 +316,15 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
   // with in-order dispatch of one wave per chunk, but no wave slot waits for the dispatcher).
   // Which wave computes an item has no influence on the item's result.
   const int n_pieces = hcnt[0];
-  // B operand: column 32 b + c, k = 8 h .. 8 h + 7 of the three weight planes, for the whole launch
-  bf16x8 wf[NB][3];
+  const float su = params[0];            // rows -> fp16 range (2^13 / A')
+  const float unscale = params[1];       // undoes the rows' and the weights' scales
+  // B operand: column 32 b + c, k = 8 h .. 8 h + 7 of the two weight planes, for the whole launch
+  f16x8 wf[NB][2];
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      wf[b][pl] = *(const bf16x8 *)(Wp + ((int64_t)pl * 32 * NB + 32 * b + c) * 16 + 8 * h);
+    for (int pl = 0; pl < 2; ++pl)
+      wf[b][pl] = __builtin_bit_cast(f16x8, *(const bf16x8 *)(Wp + ((int64_t)pl * 32 * NB + 32 * b + c) * 16 + 8 * h));
 
   // training: which mask word a lane reads (columns with c & 2: the high word, held by the lanes
   // of the upper half) and which bit of it per column block
@@ -373,24 +424,19 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
 #pragma unroll
         for (int g_ = 1; g_ < NB / 2; ++g_) mword[g_] = ux[g_ - 1];     // zero without a neighbour
       }
-      ub[3] = (live && h == 0) ? 1.f : 0.f;          // k = 7: the bias column; k = 15: nothing
-      uint32_t p1[8], p2[8], p3[8];
+      // scaled into fp16 range and cut in two: hi = rtz16(v), lo = rtz16(v - hi) (the difference is
+      // exact).  Slot k = 7 is the bias column (the value 1, i.e. 2^13 after scaling; 0 for a lane
+      // without a neighbour), k = 15 carries nothing.
+      f16x8 a1, a2;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = e < 4 ? ua[e] : ub[e - 4];
-        p1[e] = __float_as_uint(v) & 0xFFFF0000u;
-        const float r1 = v - __uint_as_float(p1[e]);
-        p2[e] = __float_as_uint(r1) & 0xFFFF0000u;
-        p3[e] = __float_as_uint(r1 - __uint_as_float(p2[e]));
+      for (int e = 0; e < 8; e += 2) {
+        float v0 = (e < 4 ? ua[e] : ub[e - 4]) * su, v1 = (e + 1 < 4 ? ua[e + 1] : ub[e - 3]) * su;
+        if (e == 6) v1 = (live && h == 0) ? H1_TOP : 0.f;
+        const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+        const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v0 - (float)hi[0], v1 - (float)hi[1]));
+        a1[e] = hi[0]; a1[e + 1] = hi[1];
+        a2[e] = lo[0]; a2[e + 1] = lo[1];
       }
-      // two high halves into one word: bytes 3:2 of the first operand above those of the second
-#define H1_PK(P, E) __builtin_amdgcn_perm(P[(E) + 1], P[E], 0x07060302u)
-      const u32x4v w1 = {H1_PK(p1, 0), H1_PK(p1, 2), H1_PK(p1, 4), H1_PK(p1, 6)};
-      const u32x4v w2 = {H1_PK(p2, 0), H1_PK(p2, 2), H1_PK(p2, 4), H1_PK(p2, 6)};
-      const u32x4v w3 = {H1_PK(p3, 0), H1_PK(p3, 2), H1_PK(p3, 4), H1_PK(p3, 6)};
-#undef H1_PK
-      const bf16x8 a1 = __builtin_bit_cast(bf16x8, w1), a2 = __builtin_bit_cast(bf16x8, w2),
-                   a3 = __builtin_bit_cast(bf16x8, w3);
       // 64 columns (two blocks) at a time, so that the accumulators and slot sums of a wide layer
       // never live together
 #pragma unroll
@@ -403,12 +449,9 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
           // smallest terms first, so that they are not rounded away against the big partial sums
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wf[b][0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[b][0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[b][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, wf[b][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[b][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[b][0], acc, 0, 0, 0);
           // acc[r] = pre-activation of neighbour (r & 3) + 8 (r >> 2) + 4 h, column 32 b + c
           float v[16];
           if (TRAIN) {
@@ -436,8 +479,8 @@ hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
             s[2 * bp + 1] += t[1][q];
             if (meta & H1_META_LAST) {
               const int r = (meta >> 4) & 63;
-              const float f = hub ? 1.f
-                                  : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, idg), r)) * scale;
+              const float f = hub ? unscale
+                                  : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, idg), r)) * (scale * unscale);
               const int64_t row = row0 + r;
               const float t0 = s[2 * bp] + __shfl_xor(s[2 * bp], 32, 64);
               const float t1 = s[2 * bp + 1] + __shfl_xor(s[2 * bp + 1], 32, 64);
@@ -485,7 +528,7 @@ h1_hub_combine_k(const int4 *__restrict__ hubs, const int *__restrict__ hcnt,
   }
 }
 
-constexpr size_t h1_planes_bytes(int64_t Fo) { return (size_t)(3 * Fo * 16) * sizeof(uint16_t); }
+constexpr size_t h1_planes_bytes(int64_t Fo) { return (size_t)(2 * Fo * 16) * sizeof(uint16_t); }
 
 }  // namespace
 
@@ -530,8 +573,9 @@ static inline size_t h1_urow_bytes(int64_t Fo, int epilogue) {
 
 extern "C" size_t gsage_segment_gather_hidden1_workspace_bytes(int64_t N, int64_t E, int64_t Fo, int epilogue) {
   if (N < 0 || E < 0 || Fo <= 0) return 0;
-  // the rows u[j], the weight planes, one partial row per piece of a hub row, the work counter
-  return gs_align_up((size_t)N * h1_urow_bytes(Fo, epilogue), 256) + gs_align_up(h1_planes_bytes(Fo), 256) +
+  // the rows u[j] and the word behind them, the weight planes, one partial row per piece of a hub
+  // row, the work counter and the two scale factors
+  return gs_align_up((size_t)(N + 1) * h1_urow_bytes(Fo, epilogue), 256) + gs_align_up(h1_planes_bytes(Fo), 256) +
          gs_align_up((size_t)h1_piece_cap(E) * (size_t)Fo * sizeof(float), 256) + 256;
 }
 
@@ -561,18 +605,23 @@ static int hidden1_impl(const void *groups, int64_t E, const int32_t *col, const
   if (N == 0) return GSAGE_OK;     // (col may be NULL: a graph without edges has nothing to index)
   hipStream_t st = gs_stream(stream);
   GsCarver carve(ws);
+  const size_t urow = h1_urow_bytes(Fo, epilogue) / 4;      // floats per row
   const float *U = u_rows;
-  if (!u_rows) U = carve.take<float>((size_t)N * (h1_urow_bytes(Fo, epilogue) / 4));
-  uint16_t *planes = carve.take<uint16_t>((size_t)(3 * Fo * 16));
+  if (!u_rows) U = carve.take<float>((size_t)(N + 1) * urow);
+  // max |u| over the table as float bits: the first word of row N, behind the last row
+  const uint32_t *u_amax = (const uint32_t *)(U + (size_t)N * urow);
+  uint16_t *planes = carve.take<uint16_t>((size_t)(2 * Fo * 16));
   float *part = carve.take<float>((size_t)h1_piece_cap(E) * (size_t)Fo);
-  int *counter = carve.take<int>(4);
+  int *counter = carve.take<int>(8);       // [0] the work counter, [4], [5] the two scale factors
+  float *params = (float *)(counter + 4);
   if (!gs_zero_async(counter, 4 * sizeof(int), st)) return GSAGE_ERR_LAUNCH;
-  hipLaunchKernelGGL(h1_pack_w_k, dim3(gs_grid(Fo * 16, 256, 16)), dim3(256), 0, st, w_l, b_l, w_r,
-                     (int)Fo, planes);
-  if (!u_rows)
+  if (!u_rows) {
+    if (!gs_zero_async(const_cast<uint32_t *>(u_amax), sizeof(uint32_t), st)) return GSAGE_ERR_LAUNCH;
     hipLaunchKernelGGL(h1_pack_u_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, agg1, x8, N,
                        train ? 1 : 0, (int)(Fo / 64), h1, (const unsigned long long *)relu_sign,
-                       const_cast<float *>(U));
+                       const_cast<float *>(U), const_cast<uint32_t *>(u_amax));
+  }
+  hipLaunchKernelGGL(h1_pack_w_k, dim3(1), dim3(256), 0, st, w_l, b_l, w_r, (int)Fo, u_amax, planes, params);
   GSAGE_CHECK_LAUNCH();
   const unsigned grid = H1_GRID_WAVES / H1_WG_WAVES;
   const H1Groups g = h1_carve(const_cast<void *>(groups), N, E);
@@ -581,7 +630,7 @@ static int hidden1_impl(const void *groups, int64_t E, const int32_t *col, const
 #define H1_LAUNCH(NB, TR)                                                                        \
   hipLaunchKernelGGL((hidden1_gather_k<NB, TR>), dim3(grid), dim3(64 * H1_WG_WAVES), 0, st,                  \
                      (const int *)g.goff, (const int2 *)g.gdesc, col, inv_deg, (const float *)U, \
-                     (const uint16_t *)planes, N, scale, out, blk, (const int2 *)g.pieces,          \
+                     (const uint16_t *)planes, (const float *)params, N, scale, out, blk, (const int2 *)g.pieces, \
                      (const int *)g.hcnt, part, counter)
   if (train && Fo == 64) H1_LAUNCH(2, true);
   else if (train && Fo == 128) H1_LAUNCH(4, true);
@@ -610,6 +659,9 @@ extern "C" int gsage_segment_gather_hidden1(const void *groups, int64_t E, const
 }
 
 extern "C" size_t gsage_hidden1_u_row_bytes(int64_t Fo, int epilogue) { return h1_urow_bytes(Fo, epilogue); }
+// the table has N + 1 rows: the first word of row N receives max |u| over the table (float bits),
+// which the gather scales its fp16 operands by
+extern "C" int64_t gsage_hidden1_u_rows(int64_t N) { return N + 1; }
 
 extern "C" size_t gsage_segment_gather_hidden1_u_workspace_bytes(int64_t E, int64_t Fo) {
   if (E < 0 || Fo <= 0) return 0;

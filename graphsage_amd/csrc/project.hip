@@ -1678,11 +1678,15 @@ project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
   const float *src = q < 2 ? agg + 4 * q : x + 4 * (q - 2);
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
-  unsigned amx = 0u;
+  unsigned amx = 0u, uamx = 0u;
   for (int64_t r0 = wave0 * 16; r0 < N; r0 += nwaves * 16) {
     const int64_t row = r0 + rl;
     const bool live = row < N;
     float4 c = live ? *(const float4 *)(src + row * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (U) {     // max |u| over the table, published behind it for the gather's fp16 scaling
+      uamx = max(max(uamx, __float_as_uint(c.x) & 0x7FFFFFFFu), __float_as_uint(c.y) & 0x7FFFFFFFu);
+      uamx = max(max(uamx, __float_as_uint(c.z) & 0x7FFFFFFFu), __float_as_uint(c.w) & 0x7FFFFFFFu);
+    }
     f32x4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -1783,6 +1787,7 @@ project_fwd_k16_k(const float *__restrict__ agg, const float *__restrict__ x,
     }
   }
   if (e.amax_out) amax_publish(amx, e.amax_out);
+  if (U && blockIdx.y == 0) amax_publish(uamx, (unsigned *)(U + N * urow));
 }
 
 // the word behind the sign bits says whether the forward kernel that ran filled them in
@@ -2264,6 +2269,10 @@ static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
     float *U = (u_rows && relu && (fo == 64 || fo == 128 || fo == 256) && (((uintptr_t)u_rows) & 15) == 0)
                    ? u_rows : nullptr;
     const int urow = (epilogue == GSAGE_EPI_RELU_DROPOUT && fo > 64) ? 32 : 16;
+    if (U) {     // the word behind the table: max |u|, raised by the kernel's waves
+      hipLaunchKernelGGL(zero_word_k, dim3(1), dim3(1), 0, st, (uint32_t *)(U + N * urow));
+      GSAGE_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(project_fwd_k16_k, dim3(g16, fo / 64), dim3(256), 0, st, agg, x, wp, N, fo, e,
                        out, relu ? relu_sign : nullptr, out_blk, U, urow);
     sign_written = relu;

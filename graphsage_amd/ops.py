@@ -242,7 +242,7 @@ def aggregate_hidden1_u(graph: GraphCSR, u_rows, w_l, b_l, w_r, epilogue, p: flo
     """:func:`aggregate_hidden1` on a row table the input layer's kernel already wrote
     (gsage_segment_gather_hidden1_u): no pack pass."""
     lib = _lib.load()
-    N, Fo = u_rows.size(0), w_l.size(0)
+    N, Fo = u_rows.size(0) - 1, w_l.size(0)        # (the table's last row holds max |u|)
     dev = u_rows.device
     with torch.cuda.device(dev):
         out = torch.empty((Fo // 64, N, 64) if out_blocked else (N, Fo), dtype=torch.float32, device=dev)
@@ -364,7 +364,7 @@ def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0
         if u_out is not None and Fi == 8 and Fo in (64, 128, 256) and not force_generic and \
                 epilogue in (_lib.EPI_RELU, _lib.EPI_RELU_DROPOUT):
             import ctypes
-            u_rows = torch.empty(N, lib.gsage_hidden1_u_row_bytes(Fo, int(epilogue)) // 4,
+            u_rows = torch.empty(lib.gsage_hidden1_u_rows(N), lib.gsage_hidden1_u_row_bytes(Fo, int(epilogue)) // 4,
                                  dtype=torch.float32, device=dev)
             wrote = ctypes.c_int(0)
         with _bracket(f"project_fwd_{Fi}x{Fo}"):

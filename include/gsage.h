@@ -134,8 +134,9 @@ int gsage_segment_gather_ew(const int32_t *rowptr, const int32_t *col, const flo
  * input features of j and their neighbour mean.  This entry point fetches the 64-byte row
  * [agg1[j] | x[j]] per neighbour instead of the 256 B..1 KB row of h1 (every fabric read is a
  * 128-byte line: half to an eighth of the line traffic, from a table of N x 64 bytes) and redoes
- * the 16 -> Fo projection on the matrix cores (bf16 MFMA on the exact three-way split of the fp32
- * operands, fp32 accumulation):
+ * the 16 -> Fo projection on the matrix cores (fp16 MFMA on a two-way split of the fp32 operands,
+ * both scaled into fp16's range by exact powers of two taken from max |u| and max |W|, fp32
+ * accumulation: errors <= ~4e-7 of the largest output; an Inf or NaN feature makes NaN rows):
  *   out[i,:] = inv_deg[i] * sum_{p in row i} act(W_l1 . agg1[col[p]] + b1 + W_r1 . x8[col[p]])
  *   agg1, x8 : fp32 [N,8], column 7 of both ZERO (the 7 input features padded to 8; the bias
  *              rides in that column), w_l / w_r : fp32 [Fo,8] padded alike, b_l [Fo]
@@ -171,10 +172,11 @@ int gsage_segment_gather_hidden1(const void *groups, int64_t E, const int32_t *c
                                  float *out, int out_blocked, void *ws, size_t ws_bytes,
                                  gsage_stream_t stream);
 
-/* The same with the row table handed in: u_rows [N, gsage_hidden1_u_row_bytes(Fo, epilogue) / 4]
+/* The same with the row table handed in: u_rows [gsage_hidden1_u_rows(N), gsage_hidden1_u_row_bytes(Fo, epilogue) / 4]
  * as gsage_project_fwd_u left it while it computed the input layer (no pack pass over agg1 / x8 /
  * the sign bits; the workspace holds only the weight planes and the hub rows' partial sums). */
 size_t gsage_hidden1_u_row_bytes(int64_t Fo, int epilogue);
+int64_t gsage_hidden1_u_rows(int64_t N);   /* N + 1: row N's first word receives max |u| (float bits) */
 size_t gsage_segment_gather_hidden1_u_workspace_bytes(int64_t E, int64_t Fo);
 int gsage_segment_gather_hidden1_u(const void *groups, int64_t E, const int32_t *col,
                                    const float *inv_deg, const float *u_rows, const float *w_l,
@@ -241,7 +243,7 @@ int gsage_project_fwd_ex(const float *agg, const float *x, const float *w_l,
                          uint64_t seed, float p, float *out, float *rnorm, void *wpack,
                          int force_generic, uint64_t *relu_sign, gsage_stream_t stream);
 /* gsage_project_fwd_ex with a third side channel, forward to the NEXT layer's aggregation:
- *   u_rows (fwd out, nullable): fp32 [N, gsage_hidden1_u_row_bytes(Fo, epilogue) / 4].  The
+ *   u_rows (fwd out, nullable): fp32 [gsage_hidden1_u_rows(N), gsage_hidden1_u_row_bytes(Fo, epilogue) / 4].  The
  *             first-layer MFMA kernel (Fi = 8, RELU / RELU_DROPOUT, Fo = 64, 128 or 256) holds
  *             each row's [agg | x] and, in training, its keep-and-positive ballots: it writes the
  *             64-byte rows gsage_segment_gather_hidden1_u fetches (graphsage.py:133-135 feeding

@@ -254,7 +254,10 @@ def test_rows_written_by_the_input_layer_kernel_equal_the_packed_ones(n, deg, fo
     box = {}
     h1, _, sign = ops.project_fwd(agg1, d[0], d[1], d[2], d[3], epilogue=epi, seed=1234 + n, p=p if train else 0.0,
                                   want_relu_sign=True, u_out=box)
-    assert box["u"] is not None and box["u"].shape == (n, 32 if train and fo > 64 else 16)
+    # (one row more than nodes: the first word of the last row is max |u| over the table)
+    assert box["u"] is not None and box["u"].shape == (n + 1, 32 if train and fo > 64 else 16)
+    want_max = torch.maximum(agg1.abs().max(), d[0].abs().max())
+    assert box["u"][n, 0].item() == want_max.item()
     got = ops.aggregate_hidden1_u(graph, box["u"], d[1], d[2], d[3], epi, p=p if train else 0.0)
     want = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], epi, p=p if train else 0.0,
                                  relu_sign=sign if train else None)
@@ -268,3 +271,32 @@ def test_rows_written_by_the_input_layer_kernel_equal_the_packed_ones(n, deg, fo
         box2 = {}
         ops.project_fwd(agg1, d[0], d[1], d[2], d[3], epilogue=epi, keep_mask=odd, p=p, u_out=box2)
         assert box2["u"] is None
+
+
+@pytest.mark.parametrize("xs,ws,bs", [(1e4, 1.0, 1.0), (1e-5, 1.0, 1.0), (1.0, 1e3, 1e3), (1.0, 1e-4, 10.0),
+                                      (300.0, 1e-3, 1e-6), (0.0, 1.0, 1.0)])
+@pytest.mark.parametrize("train", [False, True])
+def test_fp16_operand_scaling_holds_over_feature_and_weight_scales(xs, ws, bs, train):
+    """The recomputed projection runs on fp16 matrix instructions with two-part operands scaled by
+    powers of two from max |u| and max |W'|: features of size 1e4 or 1e-5, weights of size 1e3 or
+    1e-4, a bias far above or below the weights, all-zero features -- the result stays within the
+    oracle bar of the float64 value (which an unscaled fp16 operand would leave at once: 1e4 * 8
+    terms overflows, 1e-5 is subnormal)."""
+    from graphsage_amd import ops
+    n, fo, p = 6000, 64, 0.3
+    ei, x8, wl, b, wr, graph = _setup(n, fo, 12, seed=21)
+    x8, wl, wr, b = x8 * xs, wl * ws, wr * ws, b * bs
+    d = [t.cuda() for t in (x8, wl, b, wr)]
+    agg1 = ops.aggregate_mean(graph, d[0])
+    if train:
+        keep = (torch.rand(n, fo, generator=torch.Generator().manual_seed(n)) >= p).to(torch.uint8)
+        box = {}
+        _, _, sign = ops.project_fwd(agg1, d[0], d[1], d[2], d[3], epilogue=_lib.EPI_RELU_DROPOUT,
+                                     keep_mask=keep.cuda(), p=p, want_relu_sign=True, u_out=box)
+        got = ops.aggregate_hidden1_u(graph, box["u"], d[1], d[2], d[3], _lib.EPI_RELU_DROPOUT, p=p)
+        want, _ = _ref64(ei, x8, wl, b, wr, n, lambda v: torch.relu(v) * keep.double() / (1 - p))
+    else:
+        got = ops.aggregate_hidden1(graph, agg1, d[0], d[1], d[2], d[3], _lib.EPI_RELU)
+        want, _ = _ref64(ei, x8, wl, b, wr, n, torch.relu)
+    assert torch.isfinite(got).all()
+    assert_close(got, want, what="vs float64")
