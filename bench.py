@@ -402,7 +402,8 @@ def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
         f"project_fwd_8x{F}": (["project_fwd_k16_k", "sign_flag_k"],
                                "layer-1 projection + ReLU + dropout, sign bits for the backward",
                                64 * N + 4 * F * N + F * N // 8),
-        f"project_fwd_{F}x{D}": (["proj64_fwd_k", "pack_fwd_k"] if F == 64 and D == 64 else
+        f"project_fwd_{F}x{D}": (["proj64h_fwd_k", "p64h_pack_k", "proj64_fwd_k", "pack_fwd_k"]
+                                 if F == 64 and D == 64 else
                                  [f"gemm_split_k<{D // 64}>", "split_planes_k"],
                                  "layer-2 projection + L2 norm", 8 * F * N + 4 * D * N + 4 * N),
         f"project_bwd_rows_{F}x{D}": (["bwd64_fused_k<2, true>", "reduce_slabs_k", "pack_dx_k", "pack_t_k"],
@@ -579,13 +580,22 @@ def run_training(args, R):
     # pipe with each fp32 operand split exactly into three bf16 parts (fp32-equivalent results)
     dtype = "f32" if hidden < 128 or os.environ.get("GSAGE_WIDE_GEMM", "")[:1] == "f" else \
         "f32 (wide GEMMs: bf16 MFMA on 3-way split fp32 operands, fp32 accumulate)"
+    # two kernels feed the fp16 matrix pipe with each fp32 operand split into two fp16 parts, scaled by
+    # powers of two taken from max |operand| (three of the four products, fp32 accumulate; error
+    # <= ~1e-6 of the largest pre-activation, inside the 2e-6 parity bar): the recomputed layer-2
+    # aggregation and, when the range of the hidden activations is handed over, the 64 -> 64 forward
+    halves = []
     if any(a["tag"].startswith("segment_gather_hidden1") for a in anatomy):
-        dtype += ("; the layer-2 forward aggregation recomputes the 16->hidden projection of every "
-                  "gathered row on bf16 MFMA with 3-way split fp32 operands (6 of 9 products, fp32 "
-                  "accumulate: fp32-equivalent)" if dtype != "f32" else
-                  " (storage, accumulation and every GEMM in fp32, except: the layer-2 forward "
-                  "aggregation recomputes the 16->hidden projection of every gathered row on bf16 MFMA "
-                  "with 3-way split fp32 operands, 6 of 9 products, fp32 accumulate: fp32-equivalent)")
+        halves.append("the layer-2 forward aggregation, which recomputes the 16->hidden projection of "
+                      "every gathered row")
+    from graphsage_amd import ops as _ops
+    if hidden == 64 and out_dim == 64 and _ops.RANGE_WORDS and os.environ.get("GSAGE_PROJ64", "")[:1] != "f":
+        halves.append("the 64->64 forward projection")
+    if halves:
+        dtype += ("; " if dtype != "f32" else " (storage, accumulation and every other GEMM in fp32), except: ") + \
+            " and ".join(halves) + (" run on fp16 MFMA with 2-way split fp32 operands scaled by powers of "
+                                    "two, 3 of 4 products, fp32 accumulate: fp32-equivalent to ~1e-6 of "
+                                    "the largest pre-activation")
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -48,7 +48,7 @@ SIGNATURES = {
                                                  C.c_float, _p, C.c_int, _p, _sz, _p]),
     "gsage_project_fwd_u": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int, _p,
                                       C.c_uint64, C.c_float, _p, _p, _p, C.c_int, _p, _p,
-                                      C.POINTER(C.c_int), _p]),
+                                      C.POINTER(C.c_int), _p, _p, _p]),
     "gsage_project_bwd_rows_supported": (C.c_int, [_i64, _i64]),
     "gsage_project_bwd_rows": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int,
                                          C.c_float, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _i64, _p]),

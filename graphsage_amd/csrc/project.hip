@@ -1416,6 +1416,174 @@ proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
   }
 }
 
+
+// ---- the same 64 -> 64 forward on the fp16 matrix pipe (round 3).  proj64_fwd_k above is bound by
+// its matrix work (256 fp32 MFMAs of 64 cycles per tile, pipe busy 62 % of the kernel's cycles at
+// a clock the kernels around it pull down); here every fp32 operand is the sum of two fp16 parts
+// (hi = rtz16(v s), lo = rtz16(v s - hi), s a power of two that takes the largest magnitude to
+// 2^13..2^14), three of the four products are issued, smallest first, and a tile costs 96 MFMAs of
+// 32 cycles.  The activations' scale comes from a bound handed in (amax_in: max |x| as float
+// bits, published by the kernel that produced x; the mean aggregation of x cannot exceed it), the
+// weights' from their own maximum (p64h_pack_k).  Absolute operand error <= max(2^-21 |v|,
+// 2^-38 max|v|); the bias is added in fp32 in the epilogue.
+typedef short p64h_b8 __attribute__((ext_vector_type(8)));
+typedef _Float16 p64h_f8 __attribute__((ext_vector_type(8)));
+typedef _Float16 p64h_f2 __attribute__((ext_vector_type(2)));
+constexpr int P64H_PITCH = 136;          // halves per LDS row of a plane: 128 k + 8 (272 bytes: conflict-free b128 reads)
+constexpr float P64H_TOP = 8192.f;       // 2^13
+
+__device__ __forceinline__ float p64h_pow2_floor(float v, float fallback) {
+  const uint32_t e = (__float_as_uint(v) >> 23) & 255u;
+  if (!(v > 0.f) || e < 27u || e > 227u) return fallback;
+  return __uint_as_float(e << 23);
+}
+
+// planes[pl][n][k] (n < 64, k < 128: W_l | W_r) as fp16 hi / lo of W s_w; params = {s_a, 1 / (s_a s_w)}
+__global__ void __launch_bounds__(256) p64h_pack_k(const float *__restrict__ wl, const float *__restrict__ wr,
+                                                   const uint32_t *__restrict__ amax_in,
+                                                   uint16_t *__restrict__ planes, float *__restrict__ params) {
+  __shared__ float red[4];
+  auto value = [&](int e) { const int n = e >> 7, k = e & 127; return k < 64 ? wl[n * 64 + k] : wr[n * 64 + k - 64]; };
+  float m = 0.f;
+  for (int e = threadIdx.x; e < 64 * 128; e += 256) m = fmaxf(m, fabsf(value(e)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sw = P64H_TOP / p64h_pow2_floor(m, P64H_TOP);
+  for (int e = threadIdx.x; e < 64 * 128; e += 256) {
+    const float v = value(e) * sw;
+    const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+    planes[e] = __builtin_bit_cast(uint16_t, hi);
+    planes[64 * 128 + e] = __builtin_bit_cast(uint16_t, lo);
+  }
+  if (threadIdx.x == 0) {
+    const float sa = P64H_TOP / p64h_pow2_floor(__uint_as_float(*amax_in), 1.f);
+    params[0] = sa;
+    params[1] = 1.f / (sa * sw);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2)
+proj64h_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
+              const uint16_t *__restrict__ planes, const float *__restrict__ params, int64_t M,
+              EpiArgs e, float *__restrict__ out) {
+  __shared__ __align__(16) uint16_t Ah[2][64 * P64H_PITCH];   // hi / lo planes of the [agg | x] tile
+  __shared__ __align__(16) float Cs[64 * S64_DP];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const float sa = params[0], unscale = params[1];
+  // B operand of k-step s (16 k): column wn 32 + (lane & 31), k = 16 s + 8 (lane >> 5) .. + 7
+  p64h_f8 bh[8], bl[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int off = (wn * 32 + (lane & 31)) * 128 + 16 * s + 8 * (lane >> 5);
+    bh[s] = __builtin_bit_cast(p64h_f8, *(const p64h_b8 *)(planes + off));
+    bl[s] = __builtin_bit_cast(p64h_f8, *(const p64h_b8 *)(planes + 64 * 128 + off));
+  }
+  const int rsub = t >> 4, c4 = (t & 15) * 4;
+  const float4 bias = *(const float4 *)(e.bias + c4);
+  const int64_t ntiles = (M + 63) / 64;
+  unsigned amx = 0u;
+  float4 r1[4], r2[4];
+#define P64H_FETCH(ROW0)                                                    \
+  _Pragma("unroll") for (int p = 0; p < 4; ++p) {                           \
+    int64_t row = (ROW0) + p * 16 + rsub;                                   \
+    bool in = row < M;                                                      \
+    row = in ? row : 0;                                                     \
+    r1[p] = *(const float4 *)(agg + row * 64 + c4);                         \
+    r2[p] = *(const float4 *)(x + row * 64 + c4);                           \
+    if (!in) { r1[p] = make_float4(0.f, 0.f, 0.f, 0.f); r2[p] = r1[p]; }    \
+  }
+  // four fp32 values -> their scaled hi and lo halves, 8 bytes each, into the two planes
+#define P64H_SPLIT_STORE(V, ROW, COL)                                                              \
+  {                                                                                                \
+    const float v0 = (V).x * sa, v1 = (V).y * sa, v2 = (V).z * sa, v3 = (V).w * sa;                \
+    const p64h_f2 h01 = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v0, v1));           \
+    const p64h_f2 h23 = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v2, v3));           \
+    const p64h_f2 l01 = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v0 - (float)h01[0], v1 - (float)h01[1])); \
+    const p64h_f2 l23 = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v2 - (float)h23[0], v3 - (float)h23[1])); \
+    uint2 hq, lq;                                                                                  \
+    hq.x = __builtin_bit_cast(uint32_t, h01); hq.y = __builtin_bit_cast(uint32_t, h23);            \
+    lq.x = __builtin_bit_cast(uint32_t, l01); lq.y = __builtin_bit_cast(uint32_t, l23);            \
+    *(uint2 *)(Ah[0] + (ROW) * P64H_PITCH + (COL)) = hq;                                           \
+    *(uint2 *)(Ah[1] + (ROW) * P64H_PITCH + (COL)) = lq;                                           \
+  }
+  if ((int64_t)blockIdx.x < ntiles) { P64H_FETCH((int64_t)blockIdx.x * 64) }
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * 64;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      P64H_SPLIT_STORE(r1[p], p * 16 + rsub, c4)
+      P64H_SPLIT_STORE(r2[p], p * 16 + rsub, 64 + c4)
+    }
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) { P64H_FETCH((tile + gridDim.x) * 64) }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int aoff = (wm * 32 + (lane & 31)) * P64H_PITCH + 8 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const p64h_f8 ah = __builtin_bit_cast(p64h_f8, *(const p64h_b8 *)(Ah[0] + aoff + 16 * s));
+      const p64h_f8 al = __builtin_bit_cast(p64h_f8, *(const p64h_b8 *)(Ah[1] + aoff + 16 * s));
+      // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      Cs[row * S64_DP + wn * 32 + (lane & 31)] = acc[r] * unscale;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      int r = pass * 16 + rsub;
+      int64_t grow = row0 + r;
+      bool live = grow < M;
+      float4 v = *(const float4 *)(Cs + r * S64_DP + c4);
+      v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+      if (e.mode == GSAGE_EPI_RELU || e.mode == GSAGE_EPI_RELU_DROPOUT) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (e.mode == GSAGE_EPI_RELU_DROPOUT && live) {
+        uint64_t idx = (uint64_t)grow * 64u + (uint64_t)c4;
+        bool k0, k1, k2, k3;
+        if (e.keep_mask) {
+          uchar4 m = *(const uchar4 *)(e.keep_mask + idx);
+          k0 = m.x; k1 = m.y; k2 = m.z; k3 = m.w;
+        } else {
+          k0 = dropout_keep(e.seed, idx + 0, e.p); k1 = dropout_keep(e.seed, idx + 1, e.p);
+          k2 = dropout_keep(e.seed, idx + 2, e.p); k3 = dropout_keep(e.seed, idx + 3, e.p);
+        }
+        v.x = k0 ? v.x * e.inv_keep : 0.f; v.y = k1 ? v.y * e.inv_keep : 0.f;
+        v.z = k2 ? v.z * e.inv_keep : 0.f; v.w = k3 ? v.w * e.inv_keep : 0.f;
+      }
+      if (e.mode == GSAGE_EPI_L2NORM) {
+        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 4, 64);
+        ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 1, 64);
+        float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
+        v.x *= rn; v.y *= rn; v.z *= rn; v.w *= rn;
+        if (live && (t & 15) == 0 && e.rnorm) e.rnorm[grow] = rn;
+      }
+      if (live) {
+        *(float4 *)(out + grow * 64 + c4) = v;
+        amx = max(max(amx, __float_as_uint(v.x) & 0x7FFFFFFFu), __float_as_uint(v.y) & 0x7FFFFFFFu);
+        amx = max(max(amx, __float_as_uint(v.z) & 0x7FFFFFFFu), __float_as_uint(v.w) & 0x7FFFFFFFu);
+      }
+    }
+    // the next tile's staging overwrites Ah only: every wave has passed the barrier above, i.e.
+    // finished its MFMA reads of Ah; Cs is rewritten only after the next barrier
+  }
+#undef P64H_FETCH
+#undef P64H_SPLIT_STORE
+  if (e.amax_out) amax_publish(amx, e.amax_out);
+}
+
 // Fused backward of a 64 -> 64 layer: per 64-row tile
 //   dpre = epi'(grad_out)                      (registers -> LDS, never written to HBM)
 //   [grad_agg | grad_x] = dpre . [W_l | W_r]   (MFMA, weights in registers; grad_agg * scale)
@@ -2146,6 +2314,15 @@ static int wide_gemm_mode() {
   }();
   return v;
 }
+// GSAGE_PROJ64=f32 keeps the 64 -> 64 forward on the fp32 MFMA kernel even when a bound on |x| is
+// handed in (A/B measurements)
+static bool proj64_half_mode() {
+  static const bool v = [] {
+    const char *e = getenv("GSAGE_PROJ64");
+    return !(e && e[0] == 'f');
+  }();
+  return v;
+}
 static int launch_wide(int ncols, const GemmArgs &a, void *pack_base, int64_t Fi, int64_t Fo,
                        const unsigned *amax_in, hipStream_t st) {
   uint16_t *planes = (uint16_t *)((char *)pack_base + pack_f32_bytes(Fi, Fo));
@@ -2186,7 +2363,9 @@ __global__ void zero_word_k(uint32_t *w) { *w = 0u; }
 extern "C" int gsage_project_fwd_range_supported(int64_t Fi, int64_t Fo, int epilogue) {
   const bool first = Fi == 8 && Fo % 64 == 0 && (Fo == 64 || epilogue != GSAGE_EPI_L2NORM);
   const bool wide = mfma_dim(Fi) && (Fo == 128 || Fo == 256);
-  return first || wide ? 1 : 0;
+  // 64 -> 64: the fp16 two-part kernel, which runs when a bound on |x| is handed in (amax_in)
+  const bool sq64 = Fi == 64 && Fo == 64 && proj64_half_mode();
+  return first || wide || sq64 ? 1 : 0;
 }
 
 static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
@@ -2215,6 +2394,7 @@ static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
   if (amax_out) {
     // only the kernels behind gsage_project_fwd_range_supported publish it
     if (force_generic != 0 || !gsage_project_fwd_range_supported(Fi, Fo, epilogue)) return GSAGE_ERR_UNSUPPORTED;
+    if (Fi == 64 && Fo == 64 && !amax_in) return GSAGE_ERR_UNSUPPORTED;   // (only its fp16 kernel publishes)
     hipLaunchKernelGGL(zero_word_k, dim3(1), dim3(1), 0, st, amax_out);
     GSAGE_CHECK_LAUNCH();
   }
@@ -2241,10 +2421,22 @@ static int project_fwd_impl(const float *agg, const float *x, const float *w_l,
   const int pack_grid = gs_grid(2 * Fi * Fo, 256, 64);
   const bool aligned = (((uintptr_t)agg | (uintptr_t)x | (uintptr_t)out | (uintptr_t)b_l |
                          (uintptr_t)keep_mask) & 15) == 0;
-  if (force_generic == 0 && aligned && Fi == 64 && Fo == 64) {
-    hipLaunchKernelGGL(pack_fwd_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
+  if (force_generic == 0 && aligned && Fi == 64 && Fo == 64 && !in_blk && !out_blk) {
     int64_t ntiles = (N + 63) / 64;
     int grid = (int)(ntiles < S64_GRID ? ntiles : S64_GRID);
+    if (amax_in && proj64_half_mode()) {
+      // a bound on |x| came with the activations: the fp16 two-part kernel (the planes and the two
+      // scale factors live where the wide kernels keep theirs, behind the fp32 pack)
+      uint16_t *planes = (uint16_t *)((char *)wpack + pack_f32_bytes(Fi, Fo));
+      float *params = (float *)((char *)planes + pack_planes_bytes(Fi, Fo));
+      hipLaunchKernelGGL(p64h_pack_k, dim3(1), dim3(256), 0, st, w_l, w_r, amax_in, planes, params);
+      hipLaunchKernelGGL(proj64h_fwd_k, dim3(grid), dim3(256), 0, st, agg, x, (const uint16_t *)planes,
+                         (const float *)params, N, e, out);
+      GSAGE_CHECK_LAUNCH();
+      return GSAGE_OK;
+    }
+    if (amax_out) return GSAGE_ERR_UNSUPPORTED;       // the fp32 kernel does not publish max |out|
+    hipLaunchKernelGGL(pack_fwd_k, dim3(pack_grid), dim3(256), 0, st, w_l, w_r, fi, fo, wp);
     hipLaunchKernelGGL(proj64_fwd_k, dim3(grid), dim3(256), 0, st, agg, x, wp, N, e, out);
     GSAGE_CHECK_LAUNCH();
     return GSAGE_OK;
@@ -2308,9 +2500,10 @@ extern "C" int gsage_project_fwd_u(const float *agg, const float *x, const float
                                    int64_t Fo, int epilogue, const uint8_t *keep_mask,
                                    uint64_t seed, float p, float *out, float *rnorm, void *wpack,
                                    int force_generic, uint64_t *relu_sign, float *u_rows,
-                                   int *u_written, gsage_stream_t stream) {
+                                   int *u_written, const uint32_t *amax_in, uint32_t *amax_out,
+                                   gsage_stream_t stream) {
   return project_fwd_impl(agg, x, w_l, b_l, w_r, N, Fi, Fo, epilogue, keep_mask, seed, p, out, rnorm,
-                          wpack, force_generic, relu_sign, 0, 0, nullptr, nullptr, stream, u_rows,
+                          wpack, force_generic, relu_sign, 0, 0, amax_in, amax_out, stream, u_rows,
                           u_written);
 }
 

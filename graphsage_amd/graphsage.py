@@ -76,11 +76,15 @@ class SAGEConv(nn.Module):
     def run(self, x: torch.Tensor, graph: GraphCSR, epilogue: int = _lib.EPI_NONE, p: float = 0.0,
             seed: int = 0, keep_mask: Optional[torch.Tensor] = None,
             force_generic: bool = False, input_layer: bool = True,
-            agg: Optional[torch.Tensor] = None, stash: Optional[dict] = None) -> torch.Tensor:
+            agg: Optional[torch.Tensor] = None, stash: Optional[dict] = None,
+            amax_in: Optional[torch.Tensor] = None,
+            amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``input_layer``: x is the model's input (constant node features), so its padded copy is
         worth caching; hidden activations are temporaries and are padded without caching.
         ``agg``: the layer's neighbour mean computed elsewhere (no gradient wanted for it);
-        ``stash``: filled with this layer's operands for :func:`ops.aggregate_hidden1_from`."""
+        ``stash``: filled with this layer's operands for :func:`ops.aggregate_hidden1_from`;
+        ``amax_in`` / ``amax_out``: the range of the activations handed from layer to layer
+        (one int32 word each, float bits of max |x| / max |out|)."""
         w_l, w_r = self.lin_l.weight, self.lin_r.weight
         x_key = x
         width = vector_width(x.size(1))
@@ -93,7 +97,7 @@ class SAGEConv(nn.Module):
         if agg is None and self.cache_aggregation and input_layer and not x_key.requires_grad:
             agg = default_cache().aggregated(x_key, x, graph, aggregate_mean)
         return SAGELayerFunction.apply(x, w_l, self.lin_l.bias, w_r, graph, epilogue, p, seed,
-                                       keep_mask, force_generic, agg, stash)
+                                       keep_mask, force_generic, agg, stash, amax_in, amax_out)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         graph = default_cache().get(edge_index, x.size(0))
@@ -174,19 +178,45 @@ class GraphSAGE(nn.Module):
                 return ops.aggregate_hidden1_from(graph, stash)
             return None
 
+        # the range of the hidden activations travels with them (one word per layer, written on the
+        # device): a 64 -> 64 layer that is told max |x| runs on the fp16 two-part kernel
+        amax = self._range_words(x)
+
+        def amax_of(i):          # (word the layer in front of layer i published, word layer i publishes)
+            if amax is None:
+                return None, None
+            return (amax[i - 1:i] if i > 0 else None), (amax[i:i + 1] if i < len(self.convs) - 1 else None)
+
         for i, conv in enumerate(self.convs[:-1]):
+            a_in, a_out = amax_of(i)
             if training:
                 km = keep_masks[i] if keep_masks is not None else None
                 seed = 0 if km is not None else self._dropout_seed(i)
                 x = conv.run(x, graph, _lib.EPI_RELU_DROPOUT, p, seed, km, self._force_generic,
-                             input_layer=i == 0, agg=agg_for(i), stash=stash if i == 0 else None)
+                             input_layer=i == 0, agg=agg_for(i), stash=stash if i == 0 else None,
+                             amax_in=a_in, amax_out=a_out)
             else:
                 x = conv.run(x, graph, _lib.EPI_RELU, 0.0, 0, None, self._force_generic,
-                             input_layer=i == 0, agg=agg_for(i), stash=stash if i == 0 else None)
+                             input_layer=i == 0, agg=agg_for(i), stash=stash if i == 0 else None,
+                             amax_in=a_in, amax_out=a_out)
         epi = _lib.EPI_L2NORM if self.normalize_output else _lib.EPI_NONE
         last = len(self.convs) - 1
         return self.convs[-1].run(x, graph, epi, 0.0, 0, None, self._force_generic,
-                                  input_layer=last == 0, agg=agg_for(last))
+                                  input_layer=last == 0, agg=agg_for(last), amax_in=amax_of(last)[0])
+
+    def _range_words(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """One int32 word per hidden layer for max |activation| (float bits), when every layer can
+        publish / use it: the 7 (<= 8) input features into 64-wide layers all the way, 16-byte aligned
+        fp32 on the GPU (the kernels behind gsage_project_fwd_range_supported)."""
+        if self._force_generic or len(self.convs) < 2 or not x.is_cuda or x.dtype != torch.float32:
+            return None
+        if vector_width(x.size(1)) != 8 or self.hidden_channels != 64:
+            return None
+        if self.convs[-1].out_channels != 64 or not ops.RANGE_WORDS:
+            return None
+        if not _lib.load().gsage_project_fwd_range_supported(64, 64, _lib.EPI_RELU):   # GSAGE_PROJ64=f32
+            return None
+        return torch.empty(len(self.convs) - 1, dtype=torch.int32, device=x.device)
 
     # ---- wide models without autograd: hidden activations kept column-blocked (ops.py)
     def _blocked_inference_applies(self, x: torch.Tensor) -> bool:

@@ -188,6 +188,11 @@ def hidden1_will_apply(in_channels: int, hidden: int, num_nodes: int, training: 
 
 HIDDEN1_STATS = {"used": 0}      # tests / diagnostics
 
+# 64-wide models hand max |activation| from layer to layer, and a 64 -> 64 layer that is told the
+# range of its input runs on the fp16 two-part kernel (proj64h_fwd_k) instead of the fp32 MFMA one.
+# GSAGE_RANGE_WORDS=0 turns the hand-over off (every 64 -> 64 forward on the fp32 kernel).
+RANGE_WORDS = os.environ.get("GSAGE_RANGE_WORDS", "1") != "0"
+
 
 def aggregate_hidden1_from(graph: GraphCSR, stash: dict, out_blocked: bool = False) -> torch.Tensor:
     HIDDEN1_STATS["used"] += 1
@@ -338,12 +343,15 @@ def aggregate_mean_bwd(graph: GraphCSR, grad_agg: torch.Tensor, prescaled: bool 
 
 def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0, p=0.0,
                 force_generic=False, want_relu_sign: bool = False, alloc_relu_sign: bool = True,
-                u_out: Optional[dict] = None):
+                u_out: Optional[dict] = None, amax_in: Optional[torch.Tensor] = None,
+                amax_out: Optional[torch.Tensor] = None):
     """K3 forward -> (out, rnorm).  With ``want_relu_sign`` a third value is returned: the buffer
     of ``out > 0`` bits the first-layer kernel leaves for :func:`project_bwd` (None for shapes
     and epilogues that have no use for it, or when ``alloc_relu_sign`` is off).  ``u_out`` (a
     dict): asks the first-layer kernel to leave the rows the next layer's recompute gather fetches
-    (gsage_project_fwd_u); ``u_out["u"]`` is the table if the kernel that ran wrote it, else None."""
+    (gsage_project_fwd_u); ``u_out["u"]`` is the table if the kernel that ran wrote it, else None.
+    ``amax_in`` / ``amax_out``: one-word int32 tensors carrying max |activation| (float bits) from
+    layer to layer; a 64 -> 64 layer given ``amax_in`` runs on the fp16 two-part kernel."""
     lib = _lib.load()
     N, Fi = x.shape
     Fo = w_l.shape[0]
@@ -360,6 +368,9 @@ def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0
         if want_relu_sign and alloc_relu_sign and Fi <= 8 and Fo % 64 == 0 and epilogue in (_lib.EPI_RELU,
                                                                        _lib.EPI_RELU_DROPOUT):
             sign = torch.empty(lib.gsage_relu_sign_bytes(N, Fo) // 8, dtype=torch.int64, device=dev)
+        for t in (amax_in, amax_out):
+            if t is not None and (t.dtype != torch.int32 or t.numel() != 1 or not t.is_cuda):
+                raise ValueError("amax_in / amax_out must be one-element int32 tensors on the GPU")
         u_rows, wrote = None, None
         if u_out is not None and Fi == 8 and Fo in (64, 128, 256) and not force_generic and \
                 epilogue in (_lib.EPI_RELU, _lib.EPI_RELU_DROPOUT):
@@ -368,13 +379,25 @@ def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0
                                  dtype=torch.float32, device=dev)
             wrote = ctypes.c_int(0)
         with _bracket(f"project_fwd_{Fi}x{Fo}"):
-            if u_rows is not None:
-                rc = lib.gsage_project_fwd_u(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), b_l.data_ptr(),
-                                             w_r.data_ptr(), N, Fi, Fo, int(epilogue), _lib.ptr(keep_mask),
-                                             int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), out.data_ptr(),
-                                             _lib.ptr(rnorm), wpack.data_ptr(), int(force_generic),
-                                             _lib.ptr(sign), u_rows.data_ptr(), ctypes.byref(wrote),
-                                             _lib.stream_handle())
+            if u_rows is not None or amax_in is not None or amax_out is not None:
+                import ctypes
+                if wrote is None:
+                    wrote = ctypes.c_int(0)
+
+                def run(a_out):
+                    return lib.gsage_project_fwd_u(
+                        agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), b_l.data_ptr(), w_r.data_ptr(), N, Fi, Fo,
+                        int(epilogue), _lib.ptr(keep_mask), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p),
+                        out.data_ptr(), _lib.ptr(rnorm), wpack.data_ptr(), int(force_generic), _lib.ptr(sign),
+                        _lib.ptr(u_rows), ctypes.byref(wrote), _lib.ptr(amax_in), _lib.ptr(a_out),
+                        _lib.stream_handle())
+                rc = run(amax_out)
+                if rc == -2 and amax_out is not None:     # GSAGE_ERR_UNSUPPORTED
+                    # the kernel this call lands on (odd addresses, a shape without a publishing
+                    # kernel) does not leave max |out|: take it from the result instead
+                    rc = run(None)
+                    if rc == 0:
+                        amax_out.copy_((out.abs().max() if N else out.new_zeros(())).view(torch.int32))
             else:
                 rc = lib.gsage_project_fwd_ex(agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), b_l.data_ptr(),
                                               w_r.data_ptr(), N, Fi, Fo, int(epilogue), _lib.ptr(keep_mask),
@@ -382,7 +405,7 @@ def project_fwd(agg, x, w_l, b_l, w_r, epilogue=EPI_NONE, keep_mask=None, seed=0
                                               _lib.ptr(rnorm), wpack.data_ptr(), int(force_generic),
                                               _lib.ptr(sign), _lib.stream_handle())
         if u_out is not None:
-            u_out["u"] = u_rows if (wrote is not None and wrote.value == 1) else None
+            u_out["u"] = u_rows if (u_rows is not None and wrote is not None and wrote.value == 1) else None
     _lib.check(rc, "gsage_project_fwd")
     if want_relu_sign:
         return out, rnorm, sign
@@ -690,7 +713,8 @@ class SAGELayerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_l, b_l, w_r, graph: GraphCSR, epilogue: int, p: float, seed: int,
-                keep_mask, force_generic: bool, agg_cached=None, stash: Optional[dict] = None):
+                keep_mask, force_generic: bool, agg_cached=None, stash: Optional[dict] = None,
+                amax_in=None, amax_out=None):
         x = _f32c(x, "x")
         w_l, b_l, w_r = _f32c(w_l, "lin_l.weight"), _f32c(b_l, "lin_l.bias"), _f32c(w_r, "lin_r.weight")
         if x.dim() != 2 or x.size(0) != graph.num_nodes:
@@ -706,7 +730,8 @@ class SAGELayerFunction(torch.autograd.Function):
         u_box = {} if (stash is not None and stash.get("want_u")) else None
         out, rnorm, sign = project_fwd(agg, x, w_l, b_l, w_r, epilogue, keep_mask, seed, p,
                                        force_generic, want_relu_sign=True,
-                                       alloc_relu_sign=want_sign, u_out=u_box)
+                                       alloc_relu_sign=want_sign, u_out=u_box, amax_in=amax_in,
+                                       amax_out=amax_out)
         ctx.graph, ctx.epilogue, ctx.p, ctx.force_generic = graph, epilogue, p, force_generic
         ctx.save_for_backward(x, agg, out, rnorm, w_l, w_r, sign)
         if stash is not None:
@@ -728,7 +753,7 @@ class SAGELayerFunction(torch.autograd.Function):
             grad_agg, grad_x, gwl, gb, gwr = project_bwd(
                 grad_out, out, rnorm, agg, x, w_l, w_r, None, ctx.epilogue, ctx.p, True,
                 ctx.force_generic)
-            return (grad_x if need_x else None), gwl, gb, gwr, None, None, None, None, None, None, grad_agg, None
+            return (grad_x if need_x else None), gwl, gb, gwr, None, None, None, None, None, None, grad_agg, None, None, None
         live = getattr(grad_out, "_gsage_live", None)
         if (live is not None and need_x and not ctx.force_generic and SKIP_ZERO_ROWS
                 and live.version == grad_out._version and live.num_rows == x.size(0)
@@ -740,7 +765,7 @@ class SAGELayerFunction(torch.autograd.Function):
                 grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p, live)
             grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x,
                                         live_mask=live.mask)
-            return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None
+            return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None, None, None
         if live is not None and live.outside_undefined:
             # a persistent gradient table whose unlisted rows were left from an earlier step, and
             # this backward cannot go through the row list: rebuild the dense gradient (rare path)
@@ -756,7 +781,7 @@ class SAGELayerFunction(torch.autograd.Function):
             # grad_agg arrives pre-scaled by inv_deg[row]; gather it over the transposed CSR
             grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x,
                                         nz_mask=nz if SKIP_ZERO_ROWS else None)
-        return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None
+        return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None, None, None
 
 
 class SkipGramFunction(torch.autograd.Function):

@@ -249,12 +249,18 @@ int gsage_project_fwd_ex(const float *agg, const float *x, const float *w_l,
  *             64-byte rows gsage_segment_gather_hidden1_u fetches (graphsage.py:133-135 feeding
  *             the next SAGEConv's propagate) while it is at it.  *u_written (HOST int, nullable)
  *             says whether the kernel that was dispatched wrote them (unaligned operands do not
- *             take that kernel); 0 = use gsage_segment_gather_hidden1, which packs the rows itself. */
+ *             take that kernel); 0 = use gsage_segment_gather_hidden1, which packs the rows itself.
+ *   amax_in / amax_out (nullable): as in gsage_project_fwd_range, here also for the training
+ *             epilogues.  A 64 -> 64 layer that is given amax_in (max |x| as float bits; its agg is
+ *             a mean of rows of x) runs on the fp16 matrix pipe with two-part operands scaled by
+ *             that bound (three products per fp32 product, errors <= ~1e-6 of the largest
+ *             pre-activation) instead of the fp32 MFMA kernel; without it the fp32 kernel runs. */
 int gsage_project_fwd_u(const float *agg, const float *x, const float *w_l, const float *b_l,
                         const float *w_r, int64_t N, int64_t Fi, int64_t Fo, int epilogue,
                         const uint8_t *keep_mask, uint64_t seed, float p, float *out, float *rnorm,
                         void *wpack, int force_generic, uint64_t *relu_sign, float *u_rows,
-                        int *u_written, gsage_stream_t stream);
+                        int *u_written, const uint32_t *amax_in, uint32_t *amax_out,
+                        gsage_stream_t stream);
 int gsage_project_bwd_ex(const float *grad_out, const float *out, const float *rnorm,
                          const float *agg, const float *x, const float *w_l,
                          const float *w_r, const float *agg_scale, int64_t N, int64_t Fi,

@@ -130,6 +130,8 @@ def test_recompute_gather_and_range_entry_points_validate_before_touching_the_de
                                             None, 0, None, 0, None) == -1
     # gsage_project_fwd_range: eval epilogues only, in and out words must differ
     assert lib.gsage_project_fwd_range_supported(8, 256, _lib.EPI_RELU) == 1
-    assert lib.gsage_project_fwd_range_supported(64, 64, _lib.EPI_RELU) == 0
+    assert lib.gsage_project_fwd_range_supported(64, 64, _lib.EPI_RELU) == 1      # its fp16 two-part kernel
+    assert lib.gsage_project_fwd_range_supported(64, 128, _lib.EPI_L2NORM) == 1 and \
+        lib.gsage_project_fwd_range_supported(96, 64, _lib.EPI_RELU) == 0
     assert lib.gsage_project_fwd_range(None, None, None, None, None, 10, 256, 256, _lib.EPI_RELU_DROPOUT,
                                        None, None, None, 0, 0, None, None, None) == -2

@@ -226,3 +226,47 @@ def test_relu_sign_bits_replace_the_saved_output(n, fi, fo, epi):
                            False, relu_sign=sign)
         for a, b in zip(ref[2:], got2[2:]):
             assert torch.equal(a, b)
+
+
+def _float_bits(v: float) -> torch.Tensor:
+    return torch.tensor([v], dtype=torch.float32).view(torch.int32).cuda()
+
+
+@pytest.mark.parametrize("epi", EPIS)
+@pytest.mark.parametrize("n", [1, 333, 4097])
+def test_64x64_forward_on_the_fp16_pipe_when_the_input_range_is_given(n, epi):
+    """A 64 -> 64 layer that is told max |x| (amax_in) runs proj64h_fwd_k: two-part fp16 operands,
+    three products.  Same bar as the fp32 kernel, against fp64; amax_out = max |out| exactly."""
+    from graphsage_amd.ops import project_fwd
+    p = 0.3
+    agg, x, wl, bl, wr, keep, _ = _case(n, 64, 64, 77 + n)
+    agg = agg.clamp(-x.abs().max(), x.abs().max())          # a mean of rows of x stays inside its range
+    ref = _ref(*(t.double() for t in (agg, x, wl, bl, wr)), epi, keep, p).float()
+    d = [t.cuda() for t in (agg, x, wl, bl, wr)]
+    a_in, a_out = _float_bits(x.abs().max().item()), torch.full((1,), -1, dtype=torch.int32).cuda()
+    kw = dict(epilogue=epi, keep_mask=keep.cuda() if epi == _lib.EPI_RELU_DROPOUT else None,
+              p=p if epi == _lib.EPI_RELU_DROPOUT else 0.0)
+    out, _ = project_fwd(*d, amax_in=a_in, amax_out=a_out, **kw)
+    assert_close(out.cpu(), ref)
+    assert a_out.view(torch.float32).item() == out.abs().max().item()
+    plain, _ = project_fwd(*d, **kw)                        # the fp32 kernel on the same operands
+    assert_close(out.cpu(), plain.cpu())
+
+
+def test_64x64_fp16_pipe_wide_dynamic_range_and_zero_input():
+    """Operands spanning eight decades under one bound: the error stays at the scale of the largest
+    pre-activation (the documented bound).  All-zero input (bound 0): bias only, no NaN."""
+    from graphsage_amd.ops import project_fwd
+    n = 500
+    agg, x, wl, bl, wr, _, _ = _case(n, 64, 64, 5)
+    mag = 10.0 ** torch.randint(-6, 3, (n, 1)).float()
+    x, agg = x * mag, agg * mag
+    bound = max(x.abs().max().item(), agg.abs().max().item())
+    ref = _ref(*(t.double() for t in (agg, x, wl, bl, wr)), _lib.EPI_NONE, None, 0.0)
+    d = [t.cuda() for t in (agg, x, wl, bl, wr)]
+    out, _ = project_fwd(*d, amax_in=_float_bits(bound))
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-6 * ref.abs().max().item(), err
+    z = torch.zeros(n, 64).cuda()
+    out0, _ = project_fwd(z, z, d[2], d[3], d[4], amax_in=_float_bits(0.0))
+    assert torch.equal(out0.cpu(), bl.expand(n, 64))
