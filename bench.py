@@ -375,6 +375,7 @@ def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
       project_fwd_FxD            8F.N read, 4D.N + 4N written
       project_bwd_rows_FxD       R rows of grad, out, agg, x read; R rows of d agg, d x written
       project_bwd_8xF_weights_only   4F.N (gradient) + F.N/8 (sign bits) + 64N
+      hidden1_wgrad_F*           68.Le (id + 64-byte row per live edge) + slot list + R rows of d agg, d x
       skipgram_fwd               (2+K)(4D + 8).B                                 
       skipgram_bwd_*             (2+K).4D.B re-gathered + 2(2+K).4D.B read-modify-write
       touched_rows / zero_rows   8(2+K).B ids + N flag bytes + N/8 mask + 4R list / 4D.R + 4R
@@ -412,6 +413,13 @@ def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
         f"project_bwd_8x{F}_weights_only": (["dw16_mfma_k", "reduce_dw16_k"],
                                             "layer-1 weight gradients (ReLU'/dropout' from the sign bits)",
                                             4 * F * N + F * N // 8 + 64 * N),
+        f"hidden1_wgrad_F{F}": (["hidden1_wgrad_k", "wg_fill_k", "wg_count_k", "wg_reduce1_k"],
+                                "layer-1 weight gradients from layer 2's backward: one 64-byte operand row "
+                                "per live edge on the matrix cores (replaces the transposed gather + dW pass)",
+                                # per live edge its id and the 64-byte row; the slot list written and read
+                                # (a root slot and ceil(deg / 8) slots per touched row); d agg, d x and the
+                                # list entry of every touched row; the waves' partial sums
+                                (4 + 64) * Le + 16 * (2 * R + Le // 8) + R * (8 * F + 4 + 8) + 2 * 4096 * 4096),
         "skipgram_fwd": (["skipgram_fwd_vec_k<1>", "skipgram_finish_k"], "skip-gram loss forward",
                          (2 + K) * (4 * D + 8) * B),
         "skipgram_bwd_atomic": (["skipgram_bwd_k"], "skip-gram loss backward (float atomics)",

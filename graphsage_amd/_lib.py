@@ -52,6 +52,12 @@ SIGNATURES = {
     "gsage_project_bwd_rows_supported": (C.c_int, [_i64, _i64]),
     "gsage_project_bwd_rows": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int,
                                          C.c_float, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _i64, _p]),
+    "gsage_project_bwd_rows_range": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, C.c_int,
+                                               C.c_float, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _i64, _p, _p]),
+    "gsage_hidden1_wgrad_supported": (C.c_int, [_i64, C.c_int]),
+    "gsage_hidden1_wgrad_workspace_bytes": (_sz, [_i64, _i64]),
+    "gsage_hidden1_wgrad": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, C.c_int,
+                                      C.c_float, _p, _p, _p, _p, _sz, _p]),
     "gsage_touched_rows_workspace_bytes": (_sz, [_i64]),
     "gsage_touched_rows": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
     "gsage_zero_rows": (C.c_int, [_p, _p, _i64, _i64, _p, _p]),

@@ -1602,7 +1602,8 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
               const float *__restrict__ agg_scale, int64_t M_all, float inv_keep,
               float *__restrict__ grad_agg, float *__restrict__ grad_x,
               float *__restrict__ slabs, uint32_t *__restrict__ nz_mask,
-              const int *__restrict__ rows, const int *__restrict__ n_rows, int64_t rows_cap) {
+              const int *__restrict__ rows, const int *__restrict__ n_rows, int64_t rows_cap,
+              unsigned *__restrict__ gmax /* nullable: max |grad_agg|, |grad_x| stored (float bits) */) {
   // 32-row tiles, both LDS tiles double-buffered: one barrier per tile, 51 KB per workgroup and
   // <= 168 VGPRs, so three workgroups share a CU and their MFMA phases interleave
   constexpr int TR = 32;
@@ -1625,6 +1626,9 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; }
   float bsum = 0.f;
+  // (the running max |dX| lives in LDS: the kernel sits at its register limit)
+  __shared__ unsigned gmx[256];
+  gmx[t] = 0u;
   const int rsub = t >> 4, c4 = (t & 15) * 4;
   const int64_t ntiles = (M + TR - 1) / TR;
   // the tile's operands travel through registers: the loads of tile i+1 are issued right after
@@ -1741,15 +1745,22 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
     // ---- dX stores straight from the accumulators (128-byte row segments)
     {
       float *dst = (w < 2 ? grad_agg : grad_x) + (w & 1) * 32 + (lane & 31);
+      unsigned gamx = 0u;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int64_t grow = ROWS ? (int64_t)rid[buf][lr] : row0 + lr;
         const float s = w < 2 ? sc[buf][lr] : 1.f;
-        if (row0 + lr < M) dst[grow * 64] = a0[r] * s;
+        if (row0 + lr < M) {
+          const float v = a0[r] * s;
+          dst[grow * 64] = v;
+          gamx = max(gamx, __float_as_uint(v) & 0x7FFFFFFFu);
+        }
       }
+      if (gmax) gmx[t] = max(gmx[t], gamx);
     }
   }
+  if (gmax) amax_publish(gmx[t], gmax);
 #undef BWD64_FETCH
 #undef BWD64_IDS
   float *slab = slabs + (int64_t)blockIdx.x * (64 * 128 + 64);
@@ -2576,7 +2587,7 @@ static int project_bwd_impl(const float *grad_out, const float *out, const float
                             void *ws, size_t ws_bytes, int force_generic,
                             uint32_t *nz_mask, const uint64_t *relu_sign,
                             const int32_t *live_rows, const int32_t *n_live, int64_t live_cap,
-                            gsage_stream_t stream) {
+                            gsage_stream_t stream, uint32_t *gmax = nullptr) {
   if (N < 0 || Fi <= 0 || Fo <= 0 || !grad_out || !agg || !x || !w_l || !w_r || !grad_w_l ||
       !grad_b || !grad_w_r || !ws)
     return GSAGE_ERR_INVALID_ARG;
@@ -2591,6 +2602,10 @@ static int project_bwd_impl(const float *grad_out, const float *out, const float
   float *slabs = (float *)((char *)ws + pack_bytes(Fi, Fo));
   const int nslab = num_slabs(N);
 
+  if (gmax) {
+    hipLaunchKernelGGL(zero_word_k, dim3(1), dim3(1), 0, st, gmax);
+    GSAGE_CHECK_LAUNCH();
+  }
   if (N == 0) {
     if (!gs_zero_async(grad_w_l, (size_t)Fi * Fo * 4, st) ||
         !gs_zero_async(grad_w_r, (size_t)Fi * Fo * 4, st) ||
@@ -2620,7 +2635,7 @@ static int project_bwd_impl(const float *grad_out, const float *out, const float
       }
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x,
                          wp, agg_scale, N, ik, grad_agg, grad_x, slabs, nz_mask, live_rows, n_live,
-                         live_cap);
+                         live_cap, gmax);
       GSAGE_CHECK_LAUNCH();
       hipLaunchKernelGGL(reduce_slabs_k, dim3((unsigned)((2 * Fi * Fo + Fo + 63) / 64)), dim3(256), 0,
                          st, slabs, grid, fi, fo, grad_w_l, grad_w_r, grad_b);
@@ -2738,6 +2753,26 @@ extern "C" int gsage_project_bwd_rows(const float *grad_out, const float *out, c
   return project_bwd_impl(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, N, Fi, Fo, epilogue, p,
                           dpre_unused, grad_agg, grad_x, grad_w_l, grad_b, grad_w_r, ws, ws_bytes, 0,
                           nullptr, nullptr, live_rows, n_live, live_cap, stream);
+}
+
+extern "C" int gsage_project_bwd_rows_range(const float *grad_out, const float *out, const float *rnorm,
+                                            const float *agg, const float *x, const float *w_l,
+                                            const float *w_r, const float *agg_scale, int64_t N,
+                                            int64_t Fi, int64_t Fo, int epilogue, float p,
+                                            float *grad_agg, float *grad_x, float *grad_w_l,
+                                            float *grad_b, float *grad_w_r, void *ws, size_t ws_bytes,
+                                            const int32_t *live_rows, const int32_t *n_live,
+                                            int64_t live_cap, uint32_t *gmax_out,
+                                            gsage_stream_t stream) {
+  if (!gsage_project_bwd_rows_supported(Fi, Fo)) return GSAGE_ERR_UNSUPPORTED;
+  if (!live_rows || !n_live || live_cap <= 0 || !grad_agg || !grad_x || !gmax_out) return GSAGE_ERR_INVALID_ARG;
+  if ((((uintptr_t)grad_out | (uintptr_t)out | (uintptr_t)agg | (uintptr_t)x |
+        (uintptr_t)grad_agg | (uintptr_t)grad_x) & 15) != 0)
+    return GSAGE_ERR_UNSUPPORTED;
+  float *dpre_unused = epilogue != GSAGE_EPI_NONE ? grad_agg : nullptr;
+  return project_bwd_impl(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, N, Fi, Fo, epilogue, p,
+                          dpre_unused, grad_agg, grad_x, grad_w_l, grad_b, grad_w_r, ws, ws_bytes, 0,
+                          nullptr, nullptr, live_rows, n_live, live_cap, stream, gmax_out);
 }
 
 extern "C" int gsage_project_bwd(const float *grad_out, const float *out, const float *rnorm,

@@ -78,13 +78,15 @@ class SAGEConv(nn.Module):
             force_generic: bool = False, input_layer: bool = True,
             agg: Optional[torch.Tensor] = None, stash: Optional[dict] = None,
             amax_in: Optional[torch.Tensor] = None,
-            amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            amax_out: Optional[torch.Tensor] = None, upstream: Optional[dict] = None) -> torch.Tensor:
         """``input_layer``: x is the model's input (constant node features), so its padded copy is
         worth caching; hidden activations are temporaries and are padded without caching.
         ``agg``: the layer's neighbour mean computed elsewhere (no gradient wanted for it);
         ``stash``: filled with this layer's operands for :func:`ops.aggregate_hidden1_from`;
         ``amax_in`` / ``amax_out``: the range of the activations handed from layer to layer
-        (one int32 word each, float bits of max |x| / max |out|)."""
+        (one int32 word each, float bits of max |x| / max |out|);
+        ``upstream``: the stash of the layer in front, given by a caller that knows this layer to be
+        the only consumer of that layer's output (the two backwards may then meet in one kernel)."""
         w_l, w_r = self.lin_l.weight, self.lin_r.weight
         x_key = x
         width = vector_width(x.size(1))
@@ -97,7 +99,7 @@ class SAGEConv(nn.Module):
         if agg is None and self.cache_aggregation and input_layer and not x_key.requires_grad:
             agg = default_cache().aggregated(x_key, x, graph, aggregate_mean)
         return SAGELayerFunction.apply(x, w_l, self.lin_l.bias, w_r, graph, epilogue, p, seed,
-                                       keep_mask, force_generic, agg, stash, amax_in, amax_out)
+                                       keep_mask, force_generic, agg, stash, amax_in, amax_out, upstream)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         graph = default_cache().get(edge_index, x.size(0))
@@ -178,6 +180,9 @@ class GraphSAGE(nn.Module):
                 return ops.aggregate_hidden1_from(graph, stash)
             return None
 
+        def upstream_of(i):      # layer 1 is the only consumer of the input layer's output
+            return stash if i == 1 and stash is not None and stash.get("u") is not None else None
+
         # the range of the hidden activations travels with them (one word per layer, written on the
         # device): a 64 -> 64 layer that is told max |x| runs on the fp16 two-part kernel
         amax = self._range_words(x)
@@ -194,7 +199,7 @@ class GraphSAGE(nn.Module):
                 seed = 0 if km is not None else self._dropout_seed(i)
                 x = conv.run(x, graph, _lib.EPI_RELU_DROPOUT, p, seed, km, self._force_generic,
                              input_layer=i == 0, agg=agg_for(i), stash=stash if i == 0 else None,
-                             amax_in=a_in, amax_out=a_out)
+                             amax_in=a_in, amax_out=a_out, upstream=upstream_of(i))
             else:
                 x = conv.run(x, graph, _lib.EPI_RELU, 0.0, 0, None, self._force_generic,
                              input_layer=i == 0, agg=agg_for(i), stash=stash if i == 0 else None,
@@ -202,7 +207,8 @@ class GraphSAGE(nn.Module):
         epi = _lib.EPI_L2NORM if self.normalize_output else _lib.EPI_NONE
         last = len(self.convs) - 1
         return self.convs[-1].run(x, graph, epi, 0.0, 0, None, self._force_generic,
-                                  input_layer=last == 0, agg=agg_for(last), amax_in=amax_of(last)[0])
+                                  input_layer=last == 0, agg=agg_for(last), amax_in=amax_of(last)[0],
+                                  upstream=upstream_of(last))
 
     def _range_words(self, x: torch.Tensor) -> Optional[torch.Tensor]:
         """One int32 word per hidden layer for max |activation| (float bits), when every layer can

@@ -419,9 +419,11 @@ SKIP_ZERO_ROWS = os.environ.get("GSAGE_SKIP_ZERO_ROWS", "1") != "0"
 
 
 def project_bwd_rows(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue, p,
-                     live: LiveRows):
+                     live: LiveRows, gmax: Optional[torch.Tensor] = None):
     """Backward of K3 over the rows in ``live`` only (gsage_project_bwd_rows).  The rows of
-    grad_agg / grad_x outside the list are NOT written: hand them on with ``live.mask``."""
+    grad_agg / grad_x outside the list are NOT written: hand them on with ``live.mask``.
+    ``gmax`` (one int32 word on the device): receives max |grad_agg|, |grad_x| as float bits
+    (gsage_project_bwd_rows_range), which :func:`hidden1_wgrad` scales its operands by."""
     lib = _lib.load()
     N, Fi = x.shape
     Fo = w_l.shape[0]
@@ -433,15 +435,48 @@ def project_bwd_rows(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue
         ws_bytes = lib.gsage_project_bwd_workspace_bytes(N, Fi, Fo)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         with _bracket(f"project_bwd_rows_{Fi}x{Fo}"):
-            rc = lib.gsage_project_bwd_rows(grad_out.data_ptr(), _lib.ptr(out), _lib.ptr(rnorm),
-                                            agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), w_r.data_ptr(),
-                                            _lib.ptr(agg_scale), N, Fi, Fo, int(epilogue), float(p),
-                                            grad_agg.data_ptr(), grad_x.data_ptr(), gwl.data_ptr(),
-                                            gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(), ws_bytes,
-                                            live.rows.data_ptr(), live.n_rows.data_ptr(), live.cap,
-                                            _lib.stream_handle())
+            args = (grad_out.data_ptr(), _lib.ptr(out), _lib.ptr(rnorm),
+                    agg.data_ptr(), x.data_ptr(), w_l.data_ptr(), w_r.data_ptr(),
+                    _lib.ptr(agg_scale), N, Fi, Fo, int(epilogue), float(p),
+                    grad_agg.data_ptr(), grad_x.data_ptr(), gwl.data_ptr(),
+                    gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(), ws_bytes,
+                    live.rows.data_ptr(), live.n_rows.data_ptr(), live.cap)
+            if gmax is not None:
+                rc = lib.gsage_project_bwd_rows_range(*args, gmax.data_ptr(), _lib.stream_handle())
+            else:
+                rc = lib.gsage_project_bwd_rows(*args, _lib.stream_handle())
     _lib.check(rc, "gsage_project_bwd_rows")
     return grad_agg, grad_x, gwl, gb, gwr
+
+
+# The input layer wants only its weight gradients, and the layer behind it knows everything they
+# are made of: with the 64-byte row table of the forward's recompute gather at hand, the second
+# layer's backward hands (grad_agg, grad_x, the row list) to gsage_hidden1_wgrad instead of
+# scattering grad_agg to the neighbours (K7) and pushing an [N, 64] gradient through the first layer.
+# GSAGE_HIDDEN1_WGRAD=0 keeps the transposed gather + dW kernel.
+HIDDEN1_WGRAD = os.environ.get("GSAGE_HIDDEN1_WGRAD", "1") != "0"
+WGRAD_STATS = {"used": 0}      # tests / diagnostics
+
+
+def hidden1_wgrad(graph: GraphCSR, u_rows, grad_agg, grad_x, gmax, live: LiveRows, epilogue, p: float):
+    """gsage_hidden1_wgrad -> (grad_w_l [64, 8], grad_b [64], grad_w_r [64, 8]) of the input layer."""
+    lib = _lib.load()
+    N, Fo = grad_agg.shape
+    dev = grad_agg.device
+    with torch.cuda.device(dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        gwl, gb, gwr = torch.empty(Fo, 8, **f32), torch.empty(Fo, **f32), torch.empty(Fo, 8, **f32)
+        ws_bytes = lib.gsage_hidden1_wgrad_workspace_bytes(live.cap, graph.num_edges)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _bracket(f"hidden1_wgrad_F{Fo}"):
+            rc = lib.gsage_hidden1_wgrad(graph.rowptr.data_ptr(), graph.col.data_ptr(), N, graph.num_edges,
+                                         u_rows.data_ptr(), grad_agg.data_ptr(), grad_x.data_ptr(),
+                                         gmax.data_ptr(), live.rows.data_ptr(), live.n_rows.data_ptr(),
+                                         live.cap, Fo, int(epilogue), float(p), gwl.data_ptr(),
+                                         gb.data_ptr(), gwr.data_ptr(), ws.data_ptr(), ws_bytes,
+                                         _lib.stream_handle())
+    _lib.check(rc, "gsage_hidden1_wgrad")
+    return gwl, gb, gwr
 
 
 def project_bwd(grad_out, out, rnorm, agg, x, w_l, w_r, agg_scale, epilogue, p,
@@ -714,7 +749,7 @@ class SAGELayerFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_l, b_l, w_r, graph: GraphCSR, epilogue: int, p: float, seed: int,
                 keep_mask, force_generic: bool, agg_cached=None, stash: Optional[dict] = None,
-                amax_in=None, amax_out=None):
+                amax_in=None, amax_out=None, upstream: Optional[dict] = None):
         x = _f32c(x, "x")
         w_l, b_l, w_r = _f32c(w_l, "lin_l.weight"), _f32c(b_l, "lin_l.bias"), _f32c(w_r, "lin_r.weight")
         if x.dim() != 2 or x.size(0) != graph.num_nodes:
@@ -734,11 +769,16 @@ class SAGELayerFunction(torch.autograd.Function):
                                        amax_out=amax_out)
         ctx.graph, ctx.epilogue, ctx.p, ctx.force_generic = graph, epilogue, p, force_generic
         ctx.save_for_backward(x, agg, out, rnorm, w_l, w_r, sign)
+        # ``stash`` (this layer's operands, for the NEXT layer) / ``upstream`` (the stash of the layer
+        # in FRONT, handed in by a caller that vouches this layer is the only consumer of that
+        # layer's output): the way the two backwards meet in gsage_hidden1_wgrad
+        ctx.stash, ctx.upstream = stash, upstream
         if stash is not None:
             # what the next layer's aggregation can be recomputed from (aggregate_hidden1)
             stash.update(agg=agg, x=x, w_l=w_l, b_l=b_l, w_r=w_r, sign=sign, epilogue=epilogue, p=p,
                          out=out if epilogue == _lib.EPI_RELU_DROPOUT else None,
-                         u=u_box.get("u") if u_box is not None else None)
+                         u=u_box.get("u") if u_box is not None else None,
+                         weights_only=want_sign)
         return out
 
     @staticmethod
@@ -746,6 +786,20 @@ class SAGELayerFunction(torch.autograd.Function):
         x, agg, out, rnorm, w_l, w_r, sign = ctx.saved_tensors
         graph = ctx.graph
         need_x = ctx.needs_input_grad[0]
+        deferred = ctx.stash.pop("deferred", None) if ctx.stash else None
+        if deferred is not None:
+            # the layer behind this one left what its backward knows instead of a gradient: this
+            # layer's weight gradients come from there in one pass over the live edges
+            grad_agg2, grad_x2, gmax, live2 = deferred
+            gwl, gb, gwr = hidden1_wgrad(graph, ctx.stash["u"], grad_agg2, grad_x2, gmax, live2,
+                                         ctx.epilogue, ctx.p)
+            if grad_out.stride(0) != 0:
+                # ... and somebody else used this layer's output too: that part the usual way
+                _, _, gwl2, gb2, gwr2 = project_bwd(_f32c(grad_out, "grad_out"), out, rnorm, agg, x, w_l, w_r,
+                                                    graph.inv_deg, ctx.epilogue, ctx.p, False,
+                                                    ctx.force_generic, relu_sign=sign)
+                gwl, gb, gwr = gwl + gwl2, gb + gb2, gwr + gwr2
+            return None, gwl, gb, gwr, None, None, None, None, None, None, None, None, None, None, None
         grad_out = _f32c(grad_out, "grad_out")
         if ctx.needs_input_grad[10]:
             # the aggregation came from outside and wants its own gradient (row-subset layers,
@@ -753,7 +807,7 @@ class SAGELayerFunction(torch.autograd.Function):
             grad_agg, grad_x, gwl, gb, gwr = project_bwd(
                 grad_out, out, rnorm, agg, x, w_l, w_r, None, ctx.epilogue, ctx.p, True,
                 ctx.force_generic)
-            return (grad_x if need_x else None), gwl, gb, gwr, None, None, None, None, None, None, grad_agg, None, None, None
+            return (grad_x if need_x else None), gwl, gb, gwr, None, None, None, None, None, None, grad_agg, None, None, None, None
         live = getattr(grad_out, "_gsage_live", None)
         if (live is not None and need_x and not ctx.force_generic and SKIP_ZERO_ROWS
                 and live.version == grad_out._version and live.num_rows == x.size(0)
@@ -761,11 +815,25 @@ class SAGELayerFunction(torch.autograd.Function):
             # the loss backward listed the rows of grad_out that can be non-zero: walk only those
             LIVE_STATS["used"] += 1
             live.consumed = True
+            up = ctx.upstream
+            if (HIDDEN1_WGRAD and up is not None and up.get("u") is not None and up.get("weights_only")
+                    and live.rows is not None and live.cap <= x.size(0)
+                    and _lib.load().gsage_hidden1_wgrad_supported(x.size(1), int(up["epilogue"]))):
+                # the layer in front is the input layer and wants only its weight gradients: leave
+                # it (grad_agg, grad_x, the row list) and hand autograd a gradient without storage
+                WGRAD_STATS["used"] += 1
+                gmax = torch.empty(1, dtype=torch.int32, device=x.device)
+                grad_agg, grad_x, gwl, gb, gwr = project_bwd_rows(
+                    grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p, live,
+                    gmax=gmax)
+                up["deferred"] = (grad_agg, grad_x, gmax, live)
+                return (grad_out.new_zeros(()).expand(x.shape), gwl, gb, gwr, None, None, None, None, None,
+                        None, None, None, None, None, None)
             grad_agg, grad_x, gwl, gb, gwr = project_bwd_rows(
                 grad_out, out, rnorm, agg, x, w_l, w_r, graph.inv_deg, ctx.epilogue, ctx.p, live)
             grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x,
                                         live_mask=live.mask)
-            return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None, None, None
+            return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None, None, None, None
         if live is not None and live.outside_undefined:
             # a persistent gradient table whose unlisted rows were left from an earlier step, and
             # this backward cannot go through the row list: rebuild the dense gradient (rare path)
@@ -781,7 +849,7 @@ class SAGELayerFunction(torch.autograd.Function):
             # grad_agg arrives pre-scaled by inv_deg[row]; gather it over the transposed CSR
             grad_x = aggregate_mean_bwd(graph, grad_agg, prescaled=True, add_to=grad_x,
                                         nz_mask=nz if SKIP_ZERO_ROWS else None)
-        return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None, None, None
+        return grad_x, gwl, gb, gwr, None, None, None, None, None, None, None, None, None, None, None
 
 
 class SkipGramFunction(torch.autograd.Function):

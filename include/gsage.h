@@ -286,6 +286,47 @@ int gsage_project_bwd_rows(const float *grad_out, const float *out, const float 
                            float *grad_w_r, void *ws, size_t ws_bytes, const int32_t *live_rows,
                            const int32_t *n_live, int64_t live_cap, gsage_stream_t stream);
 
+/* gsage_project_bwd_rows that also publishes the range of what it wrote: *gmax_out (device word,
+ * zeroed by the call) receives max |grad_agg|, |grad_x| over the listed rows as float bits, for the
+ * fp16 scaling of gsage_hidden1_wgrad. */
+int gsage_project_bwd_rows_range(const float *grad_out, const float *out, const float *rnorm,
+                                 const float *agg, const float *x, const float *w_l, const float *w_r,
+                                 const float *agg_scale, int64_t N, int64_t Fi, int64_t Fo,
+                                 int epilogue, float p, float *grad_agg, float *grad_x,
+                                 float *grad_w_l, float *grad_b, float *grad_w_r, void *ws,
+                                 size_t ws_bytes, const int32_t *live_rows, const int32_t *n_live,
+                                 int64_t live_cap, uint32_t *gmax_out, gsage_stream_t stream);
+
+/* K7h: the INPUT layer's weight gradients straight from the backward of the layer behind it.
+ * Replaces, under autograd, the backward of graphsage.py:133-138 between the second layer's
+ * projection and the first layer's parameters: PyG scatters the gradient of layer 2's aggregation
+ * to the neighbours (an [N,64] table, two fabric lines fetched per live edge), applies
+ * ReLU'/dropout' of layer 1 and multiplies by layer 1's operands.  Only the weight gradients are
+ * wanted there (the input is the feature matrix), so the sums are taken the other way round:
+ *   dW1[c][k] = 1/(1-p) sum_{i listed} ( sum_{j in N(i)} m[j][c] grad_agg[i][c] uu[j][k]
+ *                                        + m[i][c] grad_x[i][c] uu[i][k] ),   uu[j] = [agg1[j] | 1 | x[j] | 0]
+ * -- per live edge ONE 64-byte row of the table the forward's recompute gather reads (u_rows: its
+ * padding words hold the 64 keep-and-positive bits m[j] of the stored activation), nothing written.
+ *   rowptr/col : the forward CSR (destination -> sources), N rows, E edges (N < 2^26)
+ *   u_rows     : fp32 [N + 1, 16] as gsage_project_fwd_u left it (epilogue RELU_DROPOUT, Fo = 64)
+ *   grad_agg   : fp32 [N,64], ALREADY scaled by inv_deg[row] (gsage_project_bwd_rows' agg_scale);
+ *   grad_x     : fp32 [N,64]; of both only the listed rows are read
+ *   g_amax     : max |grad_agg|, |grad_x| over the listed rows, float bits (gsage_project_bwd_rows_range)
+ *   rows/n_rows/rows_cap : the ascending row list of gsage_touched_rows
+ *   grad_w_l / grad_w_r : fp32 [64,8] (column 7, the padding, is set to 0), grad_b fp32 [64]
+ *   ws         : gsage_hidden1_wgrad_workspace_bytes(rows_cap, E) bytes
+ * Operands go through the fp16 matrix pipe as two-part values scaled by powers of two (as in
+ * gsage_segment_gather_hidden1); sums are taken in an order fixed by the row list alone: bitwise
+ * reproducible.  Only where gsage_hidden1_wgrad_supported(Fo, epilogue) (64, RELU_DROPOUT). */
+int gsage_hidden1_wgrad_supported(int64_t Fo, int epilogue);
+size_t gsage_hidden1_wgrad_workspace_bytes(int64_t rows_cap, int64_t E);
+int gsage_hidden1_wgrad(const int32_t *rowptr, const int32_t *col, int64_t N, int64_t E,
+                        const float *u_rows, const float *grad_agg, const float *grad_x,
+                        const uint32_t *g_amax, const int32_t *rows, const int32_t *n_rows,
+                        int64_t rows_cap, int64_t Fo, int epilogue, float p, float *grad_w_l,
+                        float *grad_b, float *grad_w_r, void *ws, size_t ws_bytes,
+                        gsage_stream_t stream);
+
 /* K3 forward on COLUMN-BLOCKED activations (inference of the wide models, encoder.py:181-185 with
  * hidden_dim 128/256): a blocked [N,F] matrix is F/64 separate row-major [N,64] tables laid end
  * to end (element (r,c) at (c/64)*N*64 + r*64 + c%64).  The 256-wide gather over one 10 GB table

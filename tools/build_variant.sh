@@ -7,7 +7,7 @@ src=${VARIANT_SRC:-project}
 root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $root/variants $root/build/variants
 make -C $root/graphsage_amd/csrc -j8 > /dev/null || exit 1
-extra=""; [ $src = hidden_gather ] && extra="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans"
+extra=""; { [ $src = hidden_gather ] || [ $src = hidden_wgrad ]; } && extra="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -I$root/include -Wall $extra "$@" \
   -c $root/graphsage_amd/csrc/$src.hip -o $root/build/variants/${src}_$tag.o || exit 1
 objs=$(ls $root/build/csrc/*.o | grep -v "/$src.o")
