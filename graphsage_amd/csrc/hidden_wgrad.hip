@@ -50,6 +50,10 @@ constexpr float WG_TOP = 8192.f;         // 2^13: where the largest operand magn
 #endif
 constexpr int WG_WAVES = WG_WAVES_;      // waves of the launch (one per workgroup): 256 CUs x 4 SIMDs x 6 (80 registers)
 constexpr int WG_BLOCK = WG_BLOCK_;      // groups per block (64 slot descriptors = 512 contiguous bytes); a power of two
+#ifndef WG_FLUSH_
+#define WG_FLUSH_ 8
+#endif
+constexpr int WG_FLUSH = WG_FLUSH_;      // groups per accumulation chain (a power of two)
 constexpr int WG_SLICES = 64;            // first reduction: WG_WAVES / WG_SLICES partials each
 constexpr int WG_META_ROOT = 16;         // meta = count (0..8) | root << 4 | row << 5
 
@@ -140,9 +144,19 @@ hidden1_wgrad_k(const int2 *__restrict__ desc, const int *__restrict__ n_slots, 
   const int G = (S + 3) >> 2;
   const int nblocks = (G + WG_BLOCK - 1) / WG_BLOCK;
   const float su = params[0], sg = params[1];
+  // The matrix pipe's accumulate truncates: a long chain of MFMAs into one accumulator drifts
+  // (same-sign terms, as a bias gradient has them: 1.5e-5 of the result over the ~3 000
+  // instructions of a wave's share at C4).  So the chain is cut every WG_FLUSH groups: the
+  // accumulators go to running totals by vector adds (round to nearest) and start again from zero.
+  // The totals live in LDS (16 words per lane): in registers they would cost the sixth wave per SIMD.
+  __shared__ float tot[16 * 64];
   f32x4v acc[4];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) acc[b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < 4; ++b) {
+    acc[b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tot[(4 * b + r) * 64 + lane] = 0.f;
+  }
   const int e_own = n & 7;
   // the neighbours' mask words sit where the padding columns of the row are: columns 7 (low word:
   // gradient columns 4 q + cc, cc = 0, 1) and 15 (cc = 2, 3); bit 16 (cc & 1) + q
@@ -250,6 +264,14 @@ hidden1_wgrad_k(const int2 *__restrict__ desc, const int *__restrict__ n_slots, 
       acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, acc[b], 0, 0, 0);
       acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, acc[b], 0, 0, 0);
     }
+    if ((it & (WG_FLUSH - 1)) == WG_FLUSH - 1) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tot[(4 * b + r) * 64 + lane] += acc[b][r];
+        acc[b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+      }
+    }
     d0 = d1; d1 = d2; d2 = d3;
     id1 = id2;
 #pragma unroll
@@ -264,7 +286,7 @@ hidden1_wgrad_k(const int2 *__restrict__ desc, const int *__restrict__ n_slots, 
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[(4 * kg + r) * 64 + 16 * b + n] = acc[b][r];
+    for (int r = 0; r < 4; ++r) dst[(4 * kg + r) * 64 + 16 * b + n] = tot[(4 * b + r) * 64 + lane] + acc[b][r];
 }
 
 // partial[w][1024] -> red[s][1024], s = w / (WG_WAVES / WG_SLICES), waves in ascending order

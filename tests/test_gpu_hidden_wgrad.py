@@ -89,3 +89,51 @@ def test_empty_row_list_gives_zero_gradients():
     gwl, gb, gwr = ops.hidden1_wgrad(graph, u, ga.cuda(), gx.cuda(), _gmax(ga, gx, live_ids), live,
                                      _lib.EPI_RELU_DROPOUT, p)
     assert not gwl.any() and not gb.any() and not gwr.any()
+
+
+@pytest.mark.parametrize("same_sign", [False, True])
+def test_full_size_c4_against_float64(same_sign):
+    """10 M nodes / 200 M edges, the rows a 2^20-pair batch touches (134 M live edges): float64 on the
+    GPU, edges in chunks.  Same-sign gradients are the worst case for the matrix pipe's truncating
+    accumulate (1.5e-5 before the chains were cut every 8 groups, 8e-7 after); random signs cancel
+    heavily (sums of 1e8 terms), so the bar there is the 1e-5 of the weight gradients' parity bar."""
+    from graphsage_amd import default_cache
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    nodes, p = 10_000_000, 0.3
+    dev = torch.device("cuda:0")
+    ei = powerlaw_graph(nodes, 20, seed=42, device=dev)
+    graph = default_cache().get(ei, nodes)
+    x8 = default_cache().padded(memory_features(nodes, seed=42, device=dev), 8, keep=False)
+    g = torch.Generator(device=dev).manual_seed(5)
+    wl, wr = torch.randn(64, 8, device=dev, generator=g) / 3, torch.randn(64, 8, device=dev, generator=g) / 3
+    bl = torch.randn(64, device=dev, generator=g) / 3
+    agg1 = ops.aggregate_mean(graph, x8)
+    box = {}
+    h1, _ = ops.project_fwd(agg1, x8, wl, bl, wr, epilogue=_lib.EPI_RELU_DROPOUT, seed=77, p=p, u_out=box)
+    live = ops.touched_rows(*cooccurrence_batch(ei, nodes, 1 << 20, 5, seed=1001), nodes)
+    rows = live.rows[:int(live.n_rows.item())].long()
+    is_live = torch.zeros(nodes, dtype=torch.bool, device=dev)
+    is_live[rows] = True
+    sel = is_live[ei[1]]
+    src, dst = ei[0][sel], ei[1][sel]
+    del sel, is_live
+    ga = torch.zeros(nodes, 64, device=dev)
+    gx = torch.zeros(nodes, 64, device=dev)
+    r1 = torch.randn(rows.numel(), 64, device=dev, generator=g)
+    r2 = torch.randn(rows.numel(), 64, device=dev, generator=g)
+    if same_sign:
+        r1, r2 = r1.abs(), r2.abs()
+    ga[rows] = r1 * graph.inv_deg[rows, None]          # prescaled, as gsage_project_bwd_rows leaves it
+    gx[rows] = r2
+    del r1, r2
+    gmax = torch.maximum(ga.abs().max(), gx.abs().max()).reshape(1).view(torch.int32)
+    gwl, gb, gwr = ops.hidden1_wgrad(graph, box["u"], ga, gx, gmax, live, _lib.EPI_RELU_DROPOUT, p)
+    gh = torch.zeros(nodes, 64, dtype=torch.float64, device=dev)
+    for lo in range(0, src.numel(), 10_000_000):
+        gh.index_add_(0, src[lo:lo + 10_000_000], ga[dst[lo:lo + 10_000_000]].double())
+    gh[rows] += gx[rows].double()
+    gh *= (h1 > 0)
+    gh /= (1.0 - p)
+    bar = 2e-6 if same_sign else 1e-5
+    for got, want in ((gwl, gh.t() @ agg1.double()), (gb, gh.sum(0)), (gwr, gh.t() @ x8.double())):
+        assert (got.double() - want).abs().max().item() <= bar * want.abs().max().item()
