@@ -185,19 +185,29 @@ __global__ void radix_hist_k(const int *__restrict__ keys, int64_t n, int shift,
 }
 
 // TWO: a second 32-bit payload travels with every item (the loss backward sorts (row, source,
-// weight) triples, so no permutation has to be applied afterwards)
+// weight) triples, so no permutation has to be applied afterwards).
+// The tile's items are first put in digit order inside LDS (stable: wave, round, lane), then
+// copied out by consecutive threads: an item's neighbours in LDS are its neighbours in memory as
+// long as they share its digit (16 items = 64 bytes on average at 256 digits per 4 096-item tile),
+// where a direct scatter writes 4 bytes at a time to 64 places per instruction (round 3: 224 ->
+// see DESIGN.md, K1).
 template <bool TWO>
 __global__ void __launch_bounds__(RS_T)
 radix_scatter_k(const int *__restrict__ kin, const int *__restrict__ vin, int64_t n,
                 int shift, int mask, int width, const int *__restrict__ offs,
                 int64_t ntiles, int *__restrict__ kout, int *__restrict__ vout,
                 const int *__restrict__ v2in, int *__restrict__ v2out) {
-  __shared__ int whist[RS_T / 64][256];
+  __shared__ int whist[RS_T / 64][256];     // per wave and digit: count, then next place in the LDS image
+  __shared__ int lstart[256];               // first place of a digit in the LDS image
+  __shared__ int gbase[256];                // where the tile's first item of a digit goes in memory
+  __shared__ int wsum[RS_T / 64];
+  __shared__ int sk[RS_TILE], sv[RS_TILE], sv2[TWO ? RS_TILE : 1];
   const int t = threadIdx.x, lane = gs_lane(), w = t >> 6;
   for (int i = t; i < (RS_T / 64) * 256; i += RS_T) (&whist[0][0])[i] = 0;
   __syncthreads();
 
-  const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * RS_WAVE_ITEMS;
+  const int64_t tbase = (int64_t)blockIdx.x * RS_TILE;
+  const int64_t wbase = tbase + (int64_t)w * RS_WAVE_ITEMS;
   int k[RS_ROUNDS], v[RS_ROUNDS], v2[TWO ? RS_ROUNDS : 1];
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
@@ -214,18 +224,33 @@ radix_scatter_k(const int *__restrict__ kin, const int *__restrict__ vin, int64_
     if (idx < n) atomicAdd(&whist[w][(k[r] >> shift) & mask], 1);
   }
   __syncthreads();
-  // per-digit bases: global offset of (digit, tile) then the waves in order
-  if (t <= mask) {
-    int b = offs[(int64_t)t * ntiles + blockIdx.x];
+  // per digit: the waves in order, then the digits in order (block-wide exclusive scan of the totals)
+  {
+    int tot = 0;
 #pragma unroll
     for (int ww = 0; ww < RS_T / 64; ++ww) {
       int c = whist[ww][t];
-      whist[ww][t] = b;
-      b += c;
+      whist[ww][t] = tot;
+      tot += c;
     }
+    int inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int before = 0;
+    for (int ww = 0; ww < w; ++ww) before += wsum[ww];
+    const int ls = before + inc - tot;
+    lstart[t] = ls;
+    gbase[t] = t <= mask ? offs[(int64_t)t * ntiles + blockIdx.x] : 0;
+#pragma unroll
+    for (int ww = 0; ww < RS_T / 64; ++ww) whist[ww][t] += ls;
   }
   __syncthreads();
-  // phase 2: stable ranks inside the wave, round by round
+  // phase 2: stable ranks inside the wave, round by round, into the LDS image
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; ++r) {
     int64_t idx = wbase + r * 64 + lane;
@@ -247,11 +272,24 @@ radix_scatter_k(const int *__restrict__ kin, const int *__restrict__ vin, int64_
     basev = __shfl(basev, leader & 63, 64);
     if (valid) {
       int pos = basev + rank;
-      if (kout) kout[pos] = k[r];
-      vout[pos] = v[r];
-      if (TWO) v2out[pos] = v2[r];
+      sk[pos] = k[r];
+      sv[pos] = v[r];
+      if (TWO) sv2[pos] = v2[r];
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // phase 3: out, consecutive threads to consecutive places of a digit's run
+  int64_t left = n - tbase;
+  const int cnt = left < RS_TILE ? (int)left : RS_TILE;
+#pragma unroll 4
+  for (int i = t; i < cnt; i += RS_T) {
+    const int key = sk[i];
+    const int d = (key >> shift) & mask;
+    const int pos = gbase[d] + (i - lstart[d]);
+    if (kout) kout[pos] = key;
+    vout[pos] = sv[i];
+    if (TWO) v2out[pos] = sv2[i];
   }
 }
 
