@@ -1594,7 +1594,37 @@ proj64h_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
 // rows a pair batch touched) instead of from all M rows: every other row has grad_out = 0, hence
 // dpre = 0, contributes nothing to dW/db, and its rows of grad_agg / grad_x -- which would be
 // zero -- are NOT written (the transposed gather that follows masks them by the same bits).
-template <int MODE, bool ROWS>   // 0 = no epilogue, 1 = ReLU(+dropout), 2 = L2 normalisation
+//
+// HDX (round 3): the dX half on the fp16 matrix pipe.  The kernel is bound by its fp32 MFMAs (64 per
+// tile and wave), and dX = dpre . [W_l | W_r] takes rows one by one: every dpre row is scaled by its
+// own power of two (its largest magnitude to 2^13, found while the row is staged: it sits in 16
+// lanes), split into two fp16 parts as it is read back from LDS, multiplied with the weights' two
+// fp16 planes (bwd64h_pack_k: scaled by their own maximum) in three v_mfma_f32_32x32x16_f16 per 16
+// columns of dpre -- 12 instead of 32 fp32 MFMAs -- and unscaled row by row at the store.  dW sums
+// over rows (one scale per row would have to go into the other operand), so it stays on fp32 MFMAs.
+// planes[pl][n][k] (n < 128: W_l | W_r columns, k < 64) = fp16 hi / lo of W s_w; params[0] = 1 / s_w
+__global__ void __launch_bounds__(256) bwd64h_pack_k(const float *__restrict__ wl, const float *__restrict__ wr,
+                                                     uint16_t *__restrict__ planes, float *__restrict__ params) {
+  __shared__ float red[4];
+  auto value = [&](int e) { const int n = e >> 6, k = e & 63; return n < 64 ? wl[k * 64 + n] : wr[k * 64 + n - 64]; };
+  float m = 0.f;
+  for (int e = threadIdx.x; e < 128 * 64; e += 256) m = fmaxf(m, fabsf(value(e)));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sw = P64H_TOP / p64h_pow2_floor(m, P64H_TOP);
+  for (int e = threadIdx.x; e < 128 * 64; e += 256) {
+    const float v = value(e) * sw;
+    const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+    planes[e] = __builtin_bit_cast(uint16_t, hi);
+    planes[128 * 64 + e] = __builtin_bit_cast(uint16_t, lo);
+  }
+  if (threadIdx.x == 0) params[0] = 1.f / sw;
+}
+
+template <int MODE, bool ROWS, bool HDX = false>   // 0 = no epilogue, 1 = ReLU(+dropout), 2 = L2 normalisation
 __global__ void __launch_bounds__(256, 3)
 bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
               const float *__restrict__ rnorm, const float *__restrict__ agg,
@@ -1603,7 +1633,8 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
               float *__restrict__ grad_agg, float *__restrict__ grad_x,
               float *__restrict__ slabs, uint32_t *__restrict__ nz_mask,
               const int *__restrict__ rows, const int *__restrict__ n_rows, int64_t rows_cap,
-              unsigned *__restrict__ gmax /* nullable: max |grad_agg|, |grad_x| stored (float bits) */) {
+              unsigned *__restrict__ gmax /* nullable: max |grad_agg|, |grad_x| stored (float bits) */,
+              const uint16_t *__restrict__ hplanes = nullptr, const float *__restrict__ hparams = nullptr) {
   // 32-row tiles, both LDS tiles double-buffered: one barrier per tile, 51 KB per workgroup and
   // <= 168 VGPRs, so three workgroups share a CU and their MFMA phases interleave
   constexpr int TR = 32;
@@ -1611,6 +1642,7 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
   __shared__ __align__(16) float Dp[2][TR * S64_DP];
   __shared__ float sc[2][TR];
   __shared__ int rid[2][TR];     // ROWS: the tile's row numbers, for the dX stores
+  __shared__ float rsA[2][HDX ? TR : 1], rsI[2][HDX ? TR : 1];   // HDX: a dpre row's scale, and what undoes it
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   int64_t M = M_all;             // ROWS: entries of the list; else rows of the operands
   if (ROWS) {
@@ -1618,10 +1650,23 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
     if (M > rows_cap) M = rows_cap;
   }
   // dX: wave w owns output columns 32w..32w+31 of [grad_agg | grad_x] for all 32 rows
-  float4 breg[8];
+  float4 breg[HDX ? 1 : 8];
+  p64h_f8 bh[HDX ? 4 : 1], bl[HDX ? 4 : 1];
+  float inv_sw = 1.f;
+  if (HDX) {
+    // B operand of k-step s: column 32 w + (lane & 31), k = 16 s + 8 (lane >> 5) .. + 7 of both planes
+    inv_sw = hparams[0];
 #pragma unroll
-  for (int gi = 0; gi < 8; ++gi)
-    breg[gi] = *(const float4 *)(bp + (w * 32 + (lane & 31)) * 64 + gi * 8 + (lane >> 5) * 4);
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int off = (w * 32 + (lane & 31)) * 64 + 16 * s2 + 8 * (lane >> 5);
+      bh[s2] = __builtin_bit_cast(p64h_f8, *(const p64h_b8 *)(hplanes + off));
+      bl[s2] = __builtin_bit_cast(p64h_f8, *(const p64h_b8 *)(hplanes + 128 * 64 + off));
+    }
+  } else {
+#pragma unroll
+    for (int gi = 0; gi < 8; ++gi)
+      breg[gi] = *(const float4 *)(bp + (w * 32 + (lane & 31)) * 64 + gi * 8 + (lane >> 5) * 4);
+  }
   f32x16 dw0, dw1;   // dW tiles: rows m = 0..31 / 32..63, columns 32w .. 32w+31 of [agg | x]
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; }
@@ -1692,6 +1737,17 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
         d.z = yv[p].z > 0.f ? d.z * inv_keep : 0.f; d.w = yv[p].w > 0.f ? d.w * inv_keep : 0.f;
       }
       const int r = rsub * 2 + p;   // wave w stages rows 8w .. 8w+7 of the tile
+      if (HDX) {
+        // the row's largest magnitude (its 64 values sit in 16 consecutive lanes) -> its scale
+        float m = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
+        m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 1, 64));
+        if ((t & 15) == 0) {
+          const float sr = P64H_TOP / p64h_pow2_floor(m, P64H_TOP);       // a power of two (1: nothing usable)
+          rsA[buf][r] = sr;
+          rsI[buf][r] = __uint_as_float(0x7F000000u - __float_as_uint(sr)) * inv_sw;   // 1 / sr, exactly
+        }
+      }
       *(float4 *)(Dpb + r * S64_DP + c4) = d;
       *(float4 *)(Acb + r * S64_AP + c4) = av[p];
       *(float4 *)(Acb + r * S64_AP + 64 + c4) = xv[p];
@@ -1711,6 +1767,37 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
     f32x16 a0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) a0[r] = 0.f;
+    if (HDX) {
+      // dX on the fp16 pipe: row lane & 31 of dpre, k = 16 s + 8 (lane >> 5) .. + 7, scaled and cut in two
+      const float sr = rsA[buf][lane & 31];
+      const float *drow8 = Dpb + (lane & 31) * S64_DP + (lane >> 5) * 8;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const float4 f0 = *(const float4 *)(drow8 + 16 * s2), f1 = *(const float4 *)(drow8 + 16 * s2 + 4);
+        p64h_f8 a1, a2;
+#pragma unroll
+        for (int e2 = 0; e2 < 8; e2 += 2) {
+          const float v0 = (e2 < 4 ? f4c(f0, e2) : f4c(f1, e2 - 4)) * sr;
+          const float v1 = (e2 < 4 ? f4c(f0, e2 + 1) : f4c(f1, e2 - 3)) * sr;
+          const p64h_f2 hi = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+          const p64h_f2 lo = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v0 - (float)hi[0], v1 - (float)hi[1]));
+          a1[e2] = hi[0]; a1[e2 + 1] = hi[1];
+          a2[e2] = lo[0]; a2[e2 + 1] = lo[1];
+        }
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, bh[s2], a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bl[s2], a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bh[s2], a0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int kr = 2 * kk + (lane >> 5);
+        const float d0 = Dpb[kr * S64_DP + (lane & 31)];
+        const float d1 = Dpb[kr * S64_DP + 32 + (lane & 31)];
+        const float b = Acb[kr * S64_AP + w * 32 + (lane & 31)];
+        dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, b, dw0, 0, 0, 0);
+        dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, b, dw1, 0, 0, 0);
+      }
+    } else {
     const float *drow = Dpb + (lane & 31) * S64_DP + (lane >> 5) * 4;
 #pragma unroll
     for (int gi = 0; gi < 8; ++gi) {
@@ -1727,6 +1814,7 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
           dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, b, dw1, 0, 0, 0);
         }
       }
+    }
     }
     if (t < 64) {
       // wave 0 walks the dpre tile for the bias gradient anyway: lane = column, so one ballot per
@@ -1750,7 +1838,8 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
       for (int r = 0; r < 16; ++r) {
         const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int64_t grow = ROWS ? (int64_t)rid[buf][lr] : row0 + lr;
-        const float s = w < 2 ? sc[buf][lr] : 1.f;
+        float s = w < 2 ? sc[buf][lr] : 1.f;
+        if (HDX) s *= rsI[buf][lr];
         if (row0 + lr < M) {
           const float v = a0[r] * s;
           dst[grow * 64] = v;
@@ -2334,6 +2423,14 @@ static bool proj64_half_mode() {
   }();
   return v;
 }
+// GSAGE_BWD64=f32 keeps the dX half of the fused 64 -> 64 backward (row-list form) on fp32 MFMAs
+static bool bwd64_half_mode() {
+  static const bool v = [] {
+    const char *e = getenv("GSAGE_BWD64");
+    return !(e && e[0] == 'f');
+  }();
+  return v;
+}
 static int launch_wide(int ncols, const GemmArgs &a, void *pack_base, int64_t Fi, int64_t Fo,
                        const unsigned *amax_in, hipStream_t st) {
   uint16_t *planes = (uint16_t *)((char *)pack_base + pack_f32_bytes(Fi, Fo));
@@ -2628,14 +2725,26 @@ static int project_bwd_impl(const float *grad_out, const float *out, const float
                          : epilogue == GSAGE_EPI_L2NORM ? bwd64_fused_k<2, true> : bwd64_fused_k<1, true>)
                       : (epilogue == GSAGE_EPI_NONE ? bwd64_fused_k<0, false>
                          : epilogue == GSAGE_EPI_L2NORM ? bwd64_fused_k<2, false> : bwd64_fused_k<1, false>);
+      const uint16_t *hplanes = nullptr;
+      const float *hparams = nullptr;
       if (live_rows) {
         // tiles are cut from the list: no more workgroups than the list can fill
         const int64_t lt = (live_cap + 31) / 32;
         if (lt < grid) grid = (int)(lt > 0 ? lt : 1);
+        if (bwd64_half_mode()) {
+          // dX on the fp16 pipe: the weights' two planes and their scale, behind the fp32 pack
+          uint16_t *pl = (uint16_t *)((char *)ws + pack_f32_bytes(Fi, Fo));
+          float *pr = (float *)((char *)pl + pack_planes_bytes(Fi, Fo));
+          hipLaunchKernelGGL(bwd64h_pack_k, dim3(1), dim3(256), 0, st, w_l, w_r, pl, pr);
+          hplanes = pl;
+          hparams = pr;
+          kern = epilogue == GSAGE_EPI_NONE ? bwd64_fused_k<0, true, true>
+                 : epilogue == GSAGE_EPI_L2NORM ? bwd64_fused_k<2, true, true> : bwd64_fused_k<1, true, true>;
+        }
       }
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x,
                          wp, agg_scale, N, ik, grad_agg, grad_x, slabs, nz_mask, live_rows, n_live,
-                         live_cap, gmax);
+                         live_cap, gmax, hplanes, hparams);
       GSAGE_CHECK_LAUNCH();
       hipLaunchKernelGGL(reduce_slabs_k, dim3((unsigned)((2 * Fi * Fo + Fo + 63) / 64)), dim3(256), 0,
                          st, slabs, grid, fi, fo, grad_w_l, grad_w_r, grad_b);

@@ -195,11 +195,11 @@ def test_argument_checks():
     lib = _lib.load()
     assert lib.gsage_project_fwd_range_supported(8, 256, _lib.EPI_RELU) == 1
     assert lib.gsage_project_fwd_range_supported(256, 256, _lib.EPI_L2NORM) == 1
-    assert lib.gsage_project_fwd_range_supported(64, 64, _lib.EPI_RELU) == 0
+    assert lib.gsage_project_fwd_range_supported(64, 64, _lib.EPI_RELU) == 1          # (its fp16 two-part kernel)
     assert lib.gsage_project_fwd_range_supported(8, 128, _lib.EPI_L2NORM) == 0
     agg, x, wl, b, wr = [t.cuda() for t in _case(64, f=64, seed=1)]
     word = torch.zeros(1, dtype=torch.int32, device="cuda")
-    with pytest.raises(ValueError):          # 64 -> 64 has no kernel that publishes a maximum
+    with pytest.raises(ValueError):          # 64 -> 64 publishes a maximum only from its fp16 kernel, which wants amax_in
         project_fwd_blocked(agg, x, wl, b, wr, _lib.EPI_RELU, False, False, amax_out=word)
     agg, x, wl, b, wr = [t.cuda() for t in _case(64, seed=1)]
     with pytest.raises(ValueError):          # in and out must be different words
