@@ -137,3 +137,66 @@ def test_full_size_c4_against_float64(same_sign):
     bar = 2e-6 if same_sign else 1e-5
     for got, want in ((gwl, gh.t() @ agg1.double()), (gb, gh.sum(0)), (gwr, gh.t() @ x8.double())):
         assert (got.double() - want).abs().max().item() <= bar * want.abs().max().item()
+
+
+@pytest.mark.parametrize("n,b", [(60_000, 3000), (10_000_000, 1 << 20)])
+def test_model_backward_with_and_without_the_fused_weight_gradients(n, b, monkeypatch):
+    """loss.backward() through GraphSAGE(dropout 0.3).train(): with the hand-over on, layer 2's
+    backward deposits (grad_agg, grad_x, rows) and layer 1 answers from gsage_hidden1_wgrad; off,
+    the masked transposed gather + the first layer's dW kernel run.  Same masks (the dropout stream
+    is seeded from (base, step, layer)), same deterministic loss backward: all six parameter
+    gradients agree to the 1e-5 bar, at a size the CPU oracle covers and at BASELINE C4."""
+    from graphsage_amd import GraphSAGE, SkipGramLoss
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    monkeypatch.setattr(ops, "HIDDEN1_MIN_BYTES", 0)       # the recompute gather (and its row table) at any size
+    ei = powerlaw_graph(n, 20, seed=42, device="cuda")
+    x = memory_features(n, seed=42, device="cuda")
+    t, c, neg = cooccurrence_batch(ei, n, b, 5, seed=1001)
+    torch.manual_seed(0)
+    m = GraphSAGE(7, 64, 64, 2, 0.3).cuda().train()
+    grads = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, "HIDDEN1_WGRAD", on)
+        m.set_dropout_stream(1234, 7)
+        m.zero_grad()
+        used = ops.WGRAD_STATS["used"]
+        SkipGramLoss()(m(x, ei), t, c, neg).backward()
+        assert ops.WGRAD_STATS["used"] - used == (1 if on else 0)
+        grads.append([p.grad.detach().clone() for p in m.parameters()])
+    for (name, _), a, d in zip(m.named_parameters(), *grads):
+        scale = float(d.abs().max())
+        assert scale > 0 and bool(torch.isfinite(a).all())
+        assert float((a - d).abs().max()) <= 1e-5 * scale, name
+    # the layers behind the input layer took the same path in both runs: bit-identical there
+    assert torch.equal(grads[0][3], grads[1][3]) and torch.equal(grads[0][5], grads[1][5])
+
+
+def test_captured_step_with_the_fused_weight_gradients(monkeypatch):
+    """The whole step as one HIP graph with the recompute gather and gsage_hidden1_wgrad inside
+    (work counters and range words are zeroed by kernels in the capture): four replays train like
+    four replays of a stepper captured with the hand-over off (same base seed, so the same masks
+    from the steppers' Philox generators)."""
+    from graphsage_amd import GraphSAGE, TrainStep
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    from util import assert_close
+    monkeypatch.setattr(ops, "HIDDEN1_MIN_BYTES", 0)
+    n, bs = 30_000, 2048
+    ei = powerlaw_graph(n, 12, seed=42, device="cuda")
+    x = memory_features(n, seed=42, device="cuda")
+    torch.manual_seed(0)
+    models = [GraphSAGE(7, 64, 64, 2, 0.3).cuda() for _ in range(2)]
+    models[1].load_state_dict(models[0].state_dict())
+    steppers = []
+    for m, on in zip(models, (True, False)):
+        monkeypatch.setattr(ops, "HIDDEN1_WGRAD", on)
+        ts = TrainStep(m, x, ei, seed=99)
+        used = ops.WGRAD_STATS["used"]
+        ts.capture_step(batch_size=bs, num_negatives=5, warmup=1, preserve_state=True)
+        assert (ops.WGRAD_STATS["used"] > used) == on
+        steppers.append(ts)
+    for s in range(4):
+        b = cooccurrence_batch(ei, n, bs, 5, seed=20 + s)
+        stats = [ts.step_captured(*b).clone() for ts in steppers]
+        assert_close(stats[0][:7], stats[1][:7], rtol=2e-5, floor=1e-6, what=f"stats step {s}")
+    for (name, pa), (_, pb) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        assert_close(pa, pb, rtol=1e-4, floor=2e-5, what=name)
