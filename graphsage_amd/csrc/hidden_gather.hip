@@ -298,8 +298,11 @@ static inline H1Groups h1_carve(void *buf, int64_t N, int64_t E) {
 }
 static inline int64_t h1_piece_cap(int64_t E) { return E / H1_PIECE + E / H1_HUB_T + 1; }
 
+#ifndef H1_OCC_
+#define H1_OCC_ 4
+#endif
 template <int NB, bool TRAIN>
-__global__ void __launch_bounds__(64 * H1_WG_WAVES)
+__global__ void __launch_bounds__(64 * H1_WG_WAVES, H1_OCC_)
 hidden1_gather_k(const int *__restrict__ goff, const int2 *__restrict__ gdesc,
                  const int *__restrict__ col, const float *__restrict__ inv_deg,
                  const float *__restrict__ U, const uint16_t *__restrict__ Wp,
