@@ -229,6 +229,28 @@ def measured_traffic(workload, kernel):
         return None, None, None
 
 
+# Random rows served per second by the fabric, whatever their size (32 / 64 bytes), allocation kind
+# or cache policy: tools/micro/line_fetch_probe.hip, 200 M uniformly random rows of a 10 M-row
+# table, 30 combinations, 51-53.5 G rows/s.  Every row costs one 128-byte request (RDREQ_SIZES in
+# profiles/*_pmc_hbm.json: no 32- or 64-byte requests), so this, not the byte peak, is what the
+# step's gathers run into.
+FABRIC_REQUEST_CEILING = 53.0e9
+
+
+def measured_requests(workload, kernel):
+    """128-byte fabric read requests per launch of `kernel` (profiles/*_pmc_hbm.json, RDREQ_SIZES)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_hbm.json"))):
+        best = path
+    if best is None:
+        return None
+    try:
+        return float(json.load(open(best))["RDREQ_SIZES"][kernel]["requests"])
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 # ---------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(args, hidden, out_dim, layers, K, inference=False):
     """The CPU oracle (oracle/sage_oracle.py: the op sequence PyG + loss.py execute on CPU,
@@ -407,7 +429,8 @@ def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
                                  if F == 64 and D == 64 else
                                  [f"gemm_split_k<{D // 64}>", "split_planes_k"],
                                  "layer-2 projection + L2 norm", 8 * F * N + 4 * D * N + 4 * N),
-        f"project_bwd_rows_{F}x{D}": (["bwd64_fused_k<2, true>", "reduce_slabs_k", "pack_dx_k", "pack_t_k"],
+        f"project_bwd_rows_{F}x{D}": (["bwd64_fused_k<2, true, true>" if os.environ.get("GSAGE_BWD64", "")[:1] != "f"
+                                       else "bwd64_fused_k<2, true, false>", "reduce_slabs_k", "pack_dx_k"],
                                       "fused layer-2 backward (L2-norm', dX, dW) over the touched rows",
                                       R * (4 * D * 2 + 4 * F * 2) + R * 8 * F + 4 * R),
         f"project_bwd_8x{F}_weights_only": (["dw16_mfma_k", "reduce_dw16_k"],
@@ -457,12 +480,19 @@ def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
                 traffic = sum(p[0] for p in got)
                 src, stale = got[0][1], any(p[2] for p in got)
         sec = ms * 1e-3
-        out.append({"tag": tag, "kernels": kernels, "what": what, "launches": launches, "ms": ms,
-                    "useful_bytes": useful,
-                    "useful_GBs": useful / sec / 1e9 if useful else None,
-                    "frac_useful": useful / sec / 1e9 / HBM_PEAK_GBS if useful else None,
-                    "traffic": traffic, "traffic_source": src, "traffic_stale": stale,
-                    "frac_traffic": traffic / sec / 1e9 / HBM_PEAK_GBS if traffic else None})
+        entry = {"tag": tag, "kernels": kernels, "what": what, "launches": launches, "ms": ms,
+                 "useful_bytes": useful,
+                 "useful_GBs": useful / sec / 1e9 if useful else None,
+                 "frac_useful": useful / sec / 1e9 / HBM_PEAK_GBS if useful else None,
+                 "traffic": traffic, "traffic_source": src, "traffic_stale": stale,
+                 "frac_traffic": traffic / sec / 1e9 / HBM_PEAK_GBS if traffic else None}
+        if not args.nodes and kernels and (tag.startswith("segment_gather") or tag.startswith("hidden1_wgrad")):
+            # the gathers: bound by the fabric's request rate (one 128-byte request per row), not by bytes
+            req = measured_requests(args.workload, kernels[0].partition("*")[0])
+            if req:
+                entry.update(fabric_requests=req, Grequests_per_s=req / sec / 1e9,
+                             frac_of_request_ceiling=req / sec / FABRIC_REQUEST_CEILING)
+        out.append(entry)
     out.sort(key=lambda a: -a["ms"] * a["launches"])
     return out
 
@@ -544,7 +574,12 @@ def run_training(args, R):
             "traffic_source": top["traffic_source"], "traffic_stale": top["traffic_stale"],
             "share_of_step": top["ms"] * top["launches"] / args.steps / ms_per_step,
             "note": "dominant bracket of the step by live HIP-event time; frac = useful bytes / time / "
-                    "peak (never above 1), frac_traffic = counter bytes / time / peak"})
+                    "peak (never above 1), frac_traffic = counter bytes / time / peak; for the gathers "
+                    "frac_of_request_ceiling = 128-byte fabric requests / time over the 53 G random "
+                    "rows/s the fabric serves whatever the row size (tools/micro/line_fetch_probe.hip)"})
+        for k in ("fabric_requests", "Grequests_per_s", "frac_of_request_ceiling"):
+            if k in top:
+                roofline[k] = top[k]
     agg_l2 = rec or plain
     if agg_l2 is not None:
         sm = {"what": "SURVEY 8(d): bytes of the layer-2 forward aggregation as a gather of stored rows",
@@ -594,16 +629,20 @@ def run_training(args, R):
     # aggregation and, when the range of the hidden activations is handed over, the 64 -> 64 forward
     halves = []
     if any(a["tag"].startswith("segment_gather_hidden1") for a in anatomy):
-        halves.append("the layer-2 forward aggregation, which recomputes the 16->hidden projection of "
-                      "every gathered row")
+        halves.append("the layer-2 forward aggregation (recomputes the 16->hidden projection of every "
+                      "gathered row)")
     from graphsage_amd import ops as _ops
     if hidden == 64 and out_dim == 64 and _ops.RANGE_WORDS and os.environ.get("GSAGE_PROJ64", "")[:1] != "f":
         halves.append("the 64->64 forward projection")
+    if any(a["tag"].startswith("project_bwd_rows") for a in anatomy) and os.environ.get("GSAGE_BWD64", "")[:1] != "f":
+        halves.append("the dX half of the fused 64->64 backward")
+    if any(a["tag"].startswith("hidden1_wgrad") for a in anatomy):
+        halves.append("the input layer's weight gradients (one pass over the live edges)")
     if halves:
         dtype += ("; " if dtype != "f32" else " (storage, accumulation and every other GEMM in fp32), except: ") + \
-            " and ".join(halves) + (" run on fp16 MFMA with 2-way split fp32 operands scaled by powers of "
-                                    "two, 3 of 4 products, fp32 accumulate: fp32-equivalent to ~1e-6 of "
-                                    "the largest pre-activation")
+            ", ".join(halves) + (" run on fp16 MFMA with 2-way split fp32 operands scaled by powers of "
+                                 "two, 3 of 4 products, fp32 accumulate: fp32-equivalent to ~1e-6 of "
+                                 "the largest pre-activation / gradient")
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
