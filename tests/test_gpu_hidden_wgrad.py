@@ -200,3 +200,36 @@ def test_captured_step_with_the_fused_weight_gradients(monkeypatch):
         assert_close(stats[0][:7], stats[1][:7], rtol=2e-5, floor=1e-6, what=f"stats step {s}")
     for (name, pa), (_, pb) in zip(models[0].named_parameters(), models[1].named_parameters()):
         assert_close(pa, pb, rtol=1e-4, floor=2e-5, what=name)
+
+
+def test_training_backward_through_the_fused_paths_against_the_cpu_oracle(monkeypatch):
+    """The oracle's step (PyG's op sequence + loss.py on the CPU, autograd) against the model with
+    every round-3 path forced on at a size the oracle finishes in seconds: the recompute gather on
+    the rows the input layer writes, the 64 -> 64 forward on the fp16 pipe, the row-list backward
+    with its fp16 dX, and the input layer's weight gradients from gsage_hidden1_wgrad -- injected
+    dropout masks, all six parameter gradients."""
+    from oracle import sage_oracle as O
+    from util import assert_close
+    from graphsage_amd import GraphSAGE, SkipGramLoss
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    monkeypatch.setattr(ops, "HIDDEN1_MIN_BYTES", 0)
+    n, b, k, p = 20_000, 1500, 5, 0.3
+    ei = powerlaw_graph(n, 10, seed=42)
+    x = memory_features(n, seed=42)
+    t, c, neg = cooccurrence_batch(ei, n, b, k, seed=3)
+    torch.manual_seed(0)
+    ref = O.OracleGraphSAGE(7, 64, 64, 2, p).train()
+    m = GraphSAGE(7, 64, 64, 2, p)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda().train()
+    g = torch.Generator().manual_seed(9)
+    keep = (torch.rand(n, 64, generator=g) >= p).to(torch.uint8)
+    used_w, used_h = ops.WGRAD_STATS["used"], ops.HIDDEN1_STATS["used"]
+    loss = SkipGramLoss()(m(x.cuda(), ei.cuda(), keep_masks=[keep.cuda()]), t.cuda(), c.cuda(), neg.cuda())
+    loss.backward()
+    assert ops.WGRAD_STATS["used"] == used_w + 1 and ops.HIDDEN1_STATS["used"] == used_h + 1
+    want = O.skipgram_loss(ref(x, ei, keep_masks=[keep.float()]), t, c, neg, 5.0)
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 1e-5 * abs(float(want))
+    for (name, pg), (_, pr) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(pg.grad.cpu(), pr.grad, rtol=2e-5, floor=1e-5, what=name)
