@@ -39,6 +39,22 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, float 
   return u >= p;
 }
 
+// sum / max over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), the result in every lane:
+// four rotations within the row (v_mov_dpp row_ror: vector instructions, no trip through the LDS
+// crossbar as __shfl_xor takes).  The additions pair up exactly as the xor butterfly's do, so the
+// result is bitwise the one that form gives.
+template <int N> __device__ __forceinline__ float row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); v = fmaxf(v, row_ror<1>(v));
+  return v;
+}
+
 struct EpiArgs {
   int mode;
   const float *bias;
@@ -1403,8 +1419,7 @@ proj64_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
       }
       if (e.mode == GSAGE_EPI_L2NORM) {
         float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 4, 64);
-        ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 1, 64);
+        ss = row16_sum(ss);
         float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
         v.x *= rn; v.y *= rn; v.z *= rn; v.w *= rn;
         if (live && (t & 15) == 0 && e.rnorm) e.rnorm[grow] = rn;
@@ -1564,8 +1579,7 @@ proj64h_fwd_k(const float *__restrict__ agg, const float *__restrict__ x,
       }
       if (e.mode == GSAGE_EPI_L2NORM) {
         float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 4, 64);
-        ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 1, 64);
+        ss = row16_sum(ss);
         float rn = 1.0f / fmaxf(sqrtf(ss), L2_EPS);
         v.x *= rn; v.y *= rn; v.z *= rn; v.w *= rn;
         if (live && (t & 15) == 0 && e.rnorm) e.rnorm[grow] = rn;
@@ -1712,92 +1726,104 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
     if (t < TR)                                                                    \
       scv = (agg_scale && (ROW0) + t < M) ? agg_scale[ROWS ? (int64_t)srow : (ROW0) + t] : 1.f; \
   }
+  // ---- dpre tile and [agg | x] tile of the operands in flight into LDS buffer B_
+#define BWD64_STAGE(B_)                                                                              \
+  {                                                                                                  \
+    float *Dq_ = Dp[B_], *Aq_ = Ac[B_];                                                              \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                  \
+      float4 d = gv[p];                                                                              \
+      if (MODE == 2) {                                                                               \
+        float dot = gv[p].x * yv[p].x + gv[p].y * yv[p].y + gv[p].z * yv[p].z + gv[p].w * yv[p].w;   \
+        dot = row16_sum(dot);                                                                        \
+        if (rn[p] >= 0.5f / L2_EPS) dot = 0.f;   /* clamped norm: dy/dx = I / eps */                 \
+        d.x = (gv[p].x - yv[p].x * dot) * rn[p]; d.y = (gv[p].y - yv[p].y * dot) * rn[p];            \
+        d.z = (gv[p].z - yv[p].z * dot) * rn[p]; d.w = (gv[p].w - yv[p].w * dot) * rn[p];            \
+      } else if (MODE == 1) {                                                                        \
+        d.x = yv[p].x > 0.f ? d.x * inv_keep : 0.f; d.y = yv[p].y > 0.f ? d.y * inv_keep : 0.f;      \
+        d.z = yv[p].z > 0.f ? d.z * inv_keep : 0.f; d.w = yv[p].w > 0.f ? d.w * inv_keep : 0.f;      \
+      }                                                                                              \
+      const int r = rsub * 2 + p;   /* wave w stages rows 8w .. 8w+7 of the tile */                  \
+      if (HDX) {                                                                                     \
+        /* the row's largest magnitude (its 64 values sit in 16 consecutive lanes) -> its scale */   \
+        float m = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));               \
+        m = row16_max(m);                                                                            \
+        if ((t & 15) == 0) {                                                                         \
+          const float sr = P64H_TOP / p64h_pow2_floor(m, P64H_TOP);   /* a power of two (1: nothing usable) */ \
+          rsA[B_][r] = sr;                                                                           \
+          rsI[B_][r] = __uint_as_float(0x7F000000u - __float_as_uint(sr)) * inv_sw;   /* 1 / sr, exactly */ \
+        }                                                                                            \
+      }                                                                                              \
+      *(float4 *)(Dq_ + r * S64_DP + c4) = d;                                                        \
+      *(float4 *)(Aq_ + r * S64_AP + c4) = av[p];                                                    \
+      *(float4 *)(Aq_ + r * S64_AP + 64 + c4) = xv[p];                                               \
+    }                                                                                                \
+    if (t < TR) {                                                                                    \
+      sc[B_][t] = scv;                                                                               \
+      if (ROWS) rid[B_][t] = srow;                                                                   \
+    }                                                                                                \
+  }
+  const int64_t gstep = gridDim.x;
   if ((int64_t)blockIdx.x < ntiles) {
     BWD64_IDS((int64_t)blockIdx.x * TR)
     BWD64_FETCH((int64_t)blockIdx.x * TR)
-    if ((int64_t)blockIdx.x + gridDim.x < ntiles) BWD64_IDS(((int64_t)blockIdx.x + gridDim.x) * TR)
+    if ((int64_t)blockIdx.x + gstep < ntiles) BWD64_IDS(((int64_t)blockIdx.x + gstep) * TR)
   }
   int buf = 0;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
     const int64_t row0 = tile * TR;
     float *Dpb = Dp[buf], *Acb = Ac[buf];
-    // ---- dpre tile and [agg | x] tile into LDS
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      float4 d = gv[p];
-      if (MODE == 2) {
-        float dot = gv[p].x * yv[p].x + gv[p].y * yv[p].y + gv[p].z * yv[p].z + gv[p].w * yv[p].w;
-        dot += __shfl_xor(dot, 8, 64); dot += __shfl_xor(dot, 4, 64);
-        dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 1, 64);
-        if (rn[p] >= 0.5f / L2_EPS) dot = 0.f;   // clamped norm: dy/dx = I / eps
-        d.x = (gv[p].x - yv[p].x * dot) * rn[p]; d.y = (gv[p].y - yv[p].y * dot) * rn[p];
-        d.z = (gv[p].z - yv[p].z * dot) * rn[p]; d.w = (gv[p].w - yv[p].w * dot) * rn[p];
-      } else if (MODE == 1) {
-        d.x = yv[p].x > 0.f ? d.x * inv_keep : 0.f; d.y = yv[p].y > 0.f ? d.y * inv_keep : 0.f;
-        d.z = yv[p].z > 0.f ? d.z * inv_keep : 0.f; d.w = yv[p].w > 0.f ? d.w * inv_keep : 0.f;
-      }
-      const int r = rsub * 2 + p;   // wave w stages rows 8w .. 8w+7 of the tile
-      if (HDX) {
-        // the row's largest magnitude (its 64 values sit in 16 consecutive lanes) -> its scale
-        float m = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
-        m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
-        m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 1, 64));
-        if ((t & 15) == 0) {
-          const float sr = P64H_TOP / p64h_pow2_floor(m, P64H_TOP);       // a power of two (1: nothing usable)
-          rsA[buf][r] = sr;
-          rsI[buf][r] = __uint_as_float(0x7F000000u - __float_as_uint(sr)) * inv_sw;   // 1 / sr, exactly
-        }
-      }
-      *(float4 *)(Dpb + r * S64_DP + c4) = d;
-      *(float4 *)(Acb + r * S64_AP + c4) = av[p];
-      *(float4 *)(Acb + r * S64_AP + 64 + c4) = xv[p];
-    }
-    if (t < TR) {
-      sc[buf][t] = scv;
-      if (ROWS) rid[buf][t] = srow;
-    }
+    BWD64_STAGE(buf)
     // the only barrier of the tile: the other buffer was last read before every wave reached
     // the previous one, so the next tile may be staged into it without a second barrier
     __syncthreads();
-    if (tile + gridDim.x < ntiles) {
-      BWD64_FETCH((tile + gridDim.x) * TR)
-      if (tile + 2 * (int64_t)gridDim.x < ntiles) BWD64_IDS((tile + 2 * (int64_t)gridDim.x) * TR)
+    if (tile + gstep < ntiles) {
+      BWD64_FETCH((tile + gstep) * TR)
+      if (tile + 2 * gstep < ntiles) BWD64_IDS((tile + 2 * gstep) * TR)
     }
     // ---- dX (K = 64 dpre columns) and dW (K = the tile's 32 rows), interleaved
     f32x16 a0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) a0[r] = 0.f;
     if (HDX) {
-      // dX on the fp16 pipe: row lane & 31 of dpre, k = 16 s + 8 (lane >> 5) .. + 7, scaled and cut in two
+      // dX on the fp16 pipe: row lane & 31 of dpre, k = 16 s + 8 (lane >> 5) .. + 7, scaled and cut in two.
+      // The four k-steps are spread over the sixteen dW steps (whose LDS operands are fetched one
+      // step ahead), so that the splits and the LDS reads run under the fp32 MFMAs.
       const float sr = rsA[buf][lane & 31];
       const float *drow8 = Dpb + (lane & 31) * S64_DP + (lane >> 5) * 8;
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        const float4 f0 = *(const float4 *)(drow8 + 16 * s2), f1 = *(const float4 *)(drow8 + 16 * s2 + 4);
-        p64h_f8 a1, a2;
-#pragma unroll
-        for (int e2 = 0; e2 < 8; e2 += 2) {
-          const float v0 = (e2 < 4 ? f4c(f0, e2) : f4c(f1, e2 - 4)) * sr;
-          const float v1 = (e2 < 4 ? f4c(f0, e2 + 1) : f4c(f1, e2 - 3)) * sr;
-          const p64h_f2 hi = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v0, v1));
-          const p64h_f2 lo = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v0 - (float)hi[0], v1 - (float)hi[1]));
-          a1[e2] = hi[0]; a1[e2 + 1] = hi[1];
-          a2[e2] = lo[0]; a2[e2 + 1] = lo[1];
-        }
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, bh[s2], a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bl[s2], a0, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bh[s2], a0, 0, 0, 0);
-      }
+      float d0 = Dpb[(lane >> 5) * S64_DP + (lane & 31)];
+      float d1 = Dpb[(lane >> 5) * S64_DP + 32 + (lane & 31)];
+      float bq = Acb[(lane >> 5) * S64_AP + w * 32 + (lane & 31)];
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
-        const int kr = 2 * kk + (lane >> 5);
-        const float d0 = Dpb[kr * S64_DP + (lane & 31)];
-        const float d1 = Dpb[kr * S64_DP + 32 + (lane & 31)];
-        const float b = Acb[kr * S64_AP + w * 32 + (lane & 31)];
-        dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, b, dw0, 0, 0, 0);
-        dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, b, dw1, 0, 0, 0);
+        float n0 = 0.f, n1 = 0.f, nb = 0.f;
+        if (kk < 15) {
+          const int kr = 2 * (kk + 1) + (lane >> 5);
+          n0 = Dpb[kr * S64_DP + (lane & 31)];
+          n1 = Dpb[kr * S64_DP + 32 + (lane & 31)];
+          nb = Acb[kr * S64_AP + w * 32 + (lane & 31)];
+        }
+        dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, bq, dw0, 0, 0, 0);
+        dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, bq, dw1, 0, 0, 0);
+        if ((kk & 3) == 0) {
+          const int s2 = kk >> 2;
+          const float4 f0 = *(const float4 *)(drow8 + 16 * s2), f1 = *(const float4 *)(drow8 + 16 * s2 + 4);
+          p64h_f8 a1, a2;
+#pragma unroll
+          for (int e2 = 0; e2 < 8; e2 += 2) {
+            const float v0 = (e2 < 4 ? f4c(f0, e2) : f4c(f1, e2 - 4)) * sr;
+            const float v1 = (e2 < 4 ? f4c(f0, e2 + 1) : f4c(f1, e2 - 3)) * sr;
+            const p64h_f2 hi = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+            const p64h_f2 lo = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v0 - (float)hi[0], v1 - (float)hi[1]));
+            a1[e2] = hi[0]; a1[e2 + 1] = hi[1];
+            a2[e2] = lo[0]; a2[e2 + 1] = lo[1];
+          }
+          a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, bh[s2], a0, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bl[s2], a0, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bh[s2], a0, 0, 0, 0);
+        }
+        d0 = n0; d1 = n1; bq = nb;
       }
-    } else {
+    } else if (!HDX) {
     const float *drow = Dpb + (lane & 31) * S64_DP + (lane >> 5) * 4;
 #pragma unroll
     for (int gi = 0; gi < 8; ++gi) {
@@ -1852,6 +1878,7 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
   if (gmax) amax_publish(gmx[t], gmax);
 #undef BWD64_FETCH
 #undef BWD64_IDS
+#undef BWD64_STAGE
   float *slab = slabs + (int64_t)blockIdx.x * (64 * 128 + 64);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
