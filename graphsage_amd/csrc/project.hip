@@ -39,22 +39,6 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, float 
   return u >= p;
 }
 
-// sum / max over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), the result in every lane:
-// four rotations within the row (v_mov_dpp row_ror: vector instructions, no trip through the LDS
-// crossbar as __shfl_xor takes).  The additions pair up exactly as the xor butterfly's do, so the
-// result is bitwise the one that form gives.
-template <int N> __device__ __forceinline__ float row_ror(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
-  return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); v = fmaxf(v, row_ror<1>(v));
-  return v;
-}
-
 struct EpiArgs {
   int mode;
   const float *bias;

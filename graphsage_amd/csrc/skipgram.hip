@@ -117,11 +117,7 @@ __global__ void __launch_bounds__(256) skipgram_fwd_vec_k(SgArgs a) {
 #pragma unroll
       for (int u = 0; u < 6; ++u) {
         float s = dotv[u];
-        s += __shfl_xor(s, 8, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 1, 64);
-        dotv[u] = s;
+        dotv[u] = row16_sum(s);      // (DPP row rotations: bitwise the xor butterfly's sum)
       }
       // after the xor-reduction every lane of the group holds all 6 dot products: lane u of the
       // group finishes term u (sigmoid, softplus, coefficient store) instead of lane 0 doing
