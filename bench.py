@@ -440,9 +440,9 @@ def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
                                 "layer-1 weight gradients from layer 2's backward: one 64-byte operand row "
                                 "per live edge on the matrix cores (replaces the transposed gather + dW pass)",
                                 # per live edge its id and the 64-byte row; the slot list written and read
-                                # (a root slot and ceil(deg / 8) slots per touched row); d agg, d x and the
-                                # list entry of every touched row; the waves' partial sums
-                                (4 + 64) * Le + 16 * (2 * R + Le // 8) + R * (8 * F + 4 + 8) + 2 * 4096 * 4096),
+                                # (ceil(deg / 8) slots per touched row); d agg, d x, the own 64-byte row
+                                # (root term) and the list entry of every touched row; the waves' partial sums
+                                (4 + 64) * Le + 16 * (R + Le // 8) + R * (8 * F + 4 + 8 + 64) + 2 * 6144 * 4096),
         "skipgram_fwd": (["skipgram_fwd_vec_k<1>", "skipgram_finish_k"], "skip-gram loss forward",
                          (2 + K) * (4 * D + 8) * B),
         "skipgram_bwd_atomic": (["skipgram_bwd_k"], "skip-gram loss backward (float atomics)",

@@ -22,10 +22,12 @@
 //
 // A wave takes 32 neighbours at a time (v_mfma_f32_16x16x32_f16: K = 32): four SLOTS of 8
 // neighbours of one destination each, so the B operand of a slot is that destination's gradient row
-// with the neighbours' mask bits applied.  The slots of the touched rows (plus one ROOT slot per
-// row: j = i against gx[i]) are listed once per step from the row list the loss backward leaves;
-// since nothing is stored per row, slots of any rows share an instruction and hub rows need no
-// special care.  fp32 operands go to the fp16 pipe as in the forward: two fp16 parts each, scaled by
+// with the neighbours' mask bits applied.  The slots of the touched rows are listed once per step
+// from the row list the loss backward leaves; since nothing is stored per row, slots of any rows
+// share an instruction and hub rows need no special care.  The ROOT terms (j = i against gx[i])
+// follow in a second phase of the same launch, 32 listed rows per instruction with one gradient
+// row per neighbour (as slots of their own, one "neighbour" each, they were 17 % of all slots and
+// 0.42 of the kernel's 3.44 ms).  fp32 operands go to the fp16 pipe as in the forward: two fp16 parts each, scaled by
 // powers of two from max |u| (behind the table) and max |g| (published by the kernel that writes
 // ga / gx), three of the four products.
 // The launch is a fixed number of waves, each owning every WG_WAVES-th block of 16 groups and
@@ -55,7 +57,7 @@ constexpr int WG_BLOCK = WG_BLOCK_;      // groups per block (64 slot descriptor
 #endif
 constexpr int WG_FLUSH = WG_FLUSH_;      // groups per accumulation chain (a power of two)
 constexpr int WG_SLICES = 64;            // first reduction: WG_WAVES / WG_SLICES partials each
-constexpr int WG_META_ROOT = 16;         // meta = count (0..8) | root << 4 | row << 5
+// slot descriptor: (first position in col, count (0..8) | row << 5)
 
 __device__ __forceinline__ float wg_pow2_floor(float v, float fallback) {
   const uint32_t e = (__float_as_uint(v) >> 23) & 255u;
@@ -76,7 +78,7 @@ __global__ void wg_params_k(const uint32_t *__restrict__ u_amax, const uint32_t 
   params[3] = inv_keep / (WG_TOP * sg);
 }
 
-// slots per listed row: one root slot + ceil(deg / 8); counts[cap] = 0 (the scan leaves the total there)
+// slots per listed row: ceil(deg / 8); counts[cap] = 0 (the scan leaves the total there)
 __global__ void __launch_bounds__(256) wg_count_k(const int *__restrict__ rows, const int *__restrict__ n_rows,
                                                   int64_t cap, const int *__restrict__ rowptr,
                                                   int *__restrict__ counts) {
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(256) wg_count_k(const int *__restrict__ rows, 
   int c = 0;
   if (t < n) {
     const int r = rows[t];
-    c = (rowptr[r + 1] - rowptr[r] + 7) / 8 + 1;
+    c = (rowptr[r + 1] - rowptr[r] + 7) / 8;
   }
   counts[t] = c;
 }
@@ -108,12 +110,11 @@ __global__ void __launch_bounds__(256) wg_fill_k(const int *__restrict__ rows, c
     base = soff[t];
   }
   const int ns = (deg + 7) / 8;
-  if (has) desc[base] = make_int2(0, 1 | WG_META_ROOT | (r << 5));
   const bool longrow = ns > 16;
   if (has && !longrow)
     for (int q = 0; q < ns; ++q) {
       const int left = deg - 8 * q;
-      desc[base + 1 + q] = make_int2(p0 + 8 * q, (left < 8 ? left : 8) | (r << 5));
+      desc[base + q] = make_int2(p0 + 8 * q, (left < 8 ? left : 8) | (r << 5));
     }
   // the long rows of a wave: all its lanes write the slots
   unsigned long long m = __ballot(longrow);
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(256) wg_fill_k(const int *__restrict__ rows, c
     const int ns_ = (d_ + 7) / 8;
     for (int q = lane; q < ns_; q += 64) {
       const int left = d_ - 8 * q;
-      desc[b_ + 1 + q] = make_int2(p_ + 8 * q, (left < 8 ? left : 8) | (r_ << 5));
+      desc[b_ + q] = make_int2(p_ + 8 * q, (left < 8 ? left : 8) | (r_ << 5));
     }
   }
 }
@@ -138,7 +139,8 @@ __global__ void __launch_bounds__(256) wg_fill_k(const int *__restrict__ rows, c
 __global__ void __launch_bounds__(64, WG_OCC_)
 hidden1_wgrad_k(const int2 *__restrict__ desc, const int *__restrict__ n_slots, const int *__restrict__ col,
                 const float *__restrict__ U, const float *__restrict__ ga, const float *__restrict__ gx,
-                const float *__restrict__ params, float *__restrict__ partial) {
+                const float *__restrict__ params, float *__restrict__ partial,
+                const int *__restrict__ rows, const int *__restrict__ n_rows, int rows_cap) {
   const int lane = threadIdx.x, n = lane & 15, kg = lane >> 4;
   const int S = *n_slots;
   const int G = (S + 3) >> 2;
@@ -184,11 +186,7 @@ hidden1_wgrad_k(const int2 *__restrict__ desc, const int *__restrict__ n_slots, 
 #define WG_LOAD_COL(DST, D)                                                \
   {                                                                        \
     DST = -1;                                                              \
-    if ((D).y & WG_META_ROOT) {                                            \
-      if (e_own == 0) DST = (D).y >> 5;                                    \
-    } else if (e_own < ((D).y & 15)) {                                     \
-      DST = col[(D).x + e_own];                                            \
-    }                                                                      \
+    if (e_own < ((D).y & 15)) DST = col[(D).x + e_own];                    \
   }
 #define WG_LOAD_ROWS(V, GQ, IDOWN, D)                                      \
   {                                                                        \
@@ -197,7 +195,7 @@ hidden1_wgrad_k(const int2 *__restrict__ desc, const int *__restrict__ n_slots, 
       V[e] = 0u;                                                           \
       if (id_ >= 0) V[e] = *(const uint32_t *)((const char *)U + ((uint32_t)id_ * 64u + u_lane)); \
     }                                                                      \
-    const float *g_ = (((D).y & WG_META_ROOT) ? gx : ga) + (int64_t)((D).y >> 5) * 64 + n; \
+    const float *g_ = ga + (int64_t)((D).y >> 5) * 64 + n;                 \
     _Pragma("unroll") for (int b = 0; b < 4; ++b) GQ[b] = ((D).y & 15) ? g_[16 * b] : 0.f; \
   }
 
@@ -282,6 +280,74 @@ hidden1_wgrad_k(const int2 *__restrict__ desc, const int *__restrict__ n_slots, 
 #undef WG_LOAD_DESC
 #undef WG_LOAD_COL
 #undef WG_LOAD_ROWS
+  // ---- phase 2, the root terms: group gr = the listed rows 32 gr .. 32 gr + 31 as 32 "neighbours"
+  // (j = the row itself), each against its OWN gradient row gx[j]; wave w takes gr = w, w + W, ...
+  {
+    int Rn = *n_rows;
+    if (Rn > rows_cap) Rn = rows_cap;
+    const int RG = (Rn + 31) >> 5;
+    auto own_row = [&](int gr) {
+      const int t_ = 32 * gr + 8 * kg + e_own;
+      return gr < RG && t_ < Rn ? rows[t_] : -1;
+    };
+    int rid = own_row((int)blockIdx.x), trip = 0;
+    for (int gr = blockIdx.x; gr < RG; gr += gridDim.x, ++trip) {
+      const int rid_next = own_row(gr + (int)gridDim.x);
+      int id[8];
+      uint32_t uv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        id[e] = __shfl(rid, 16 * kg + e, 64);
+        uv[e] = 0u;
+        if (id[e] >= 0) uv[e] = *(const uint32_t *)((const char *)U + ((uint32_t)id[e] * 64u + u_lane));
+      }
+      uint32_t wv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[e] = (uint32_t)__builtin_amdgcn_ds_bpermute(msrc, (int)uv[e]);
+      f16x8 a1, a2;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const float v0 = special ? spec : __uint_as_float(uv[e]) * su;
+        const float v1 = special ? spec : __uint_as_float(uv[e + 1]) * su;
+        const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+        const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v0 - (float)hi[0], v1 - (float)hi[1]));
+        a1[e] = hi[0]; a1[e + 1] = hi[1];
+        a2[e] = lo[0]; a2[e + 1] = lo[1];
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        // (fetched block by block: with the next block's values in flight as well the kernel spills)
+        float gc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gc[e] = id[e] >= 0 ? gx[(int64_t)id[e] * 64 + 16 * b + n] : 0.f;
+        u32x4v b1, b2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float s0 = gc[2 * q] * sg, s1 = gc[2 * q + 1] * sg;
+          const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s0, s1));
+          const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(s0 - (float)hi[0], s1 - (float)hi[1]));
+          const uint32_t t0 = (uint32_t)__builtin_amdgcn_sbfe((int)wv[2 * q], bit0 + 4 * b, 1);
+          const uint32_t t1 = (uint32_t)__builtin_amdgcn_sbfe((int)wv[2 * q + 1], bit0 + 4 * b, 1);
+          const uint32_t m = (t0 & 0xFFFFu) | (t1 & 0xFFFF0000u);
+          b1[q] = m & __builtin_bit_cast(uint32_t, hi);
+          b2[q] = m & lo;
+        }
+        const f16x8 bh = __builtin_bit_cast(f16x8, b1), bl = __builtin_bit_cast(f16x8, b2);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bh, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, acc[b], 0, 0, 0);
+      }
+      if ((trip & (WG_FLUSH - 1)) == WG_FLUSH - 1) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[(4 * b + r) * 64 + lane] += acc[b][r];
+          acc[b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      rid = rid_next;
+    }
+  }
   float *dst = partial + (int64_t)blockIdx.x * 1024;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
@@ -323,8 +389,8 @@ struct WgradWs {
   float *red;        // [WG_SLICES][16][64]
   size_t bytes;
 };
-// a listed row has 1 + ceil(deg / 8) <= 2 + deg / 8 slots
-static inline int64_t wg_max_slots(int64_t cap, int64_t E) { return 2 * cap + E / 8 + 4; }
+// a listed row has ceil(deg / 8) <= 1 + deg / 8 slots
+static inline int64_t wg_max_slots(int64_t cap, int64_t E) { return cap + E / 8 + 4; }
 static inline WgradWs wg_carve(void *buf, int64_t cap, int64_t E) {
   GsCarver c(buf);
   WgradWs w;
@@ -383,7 +449,7 @@ extern "C" int gsage_hidden1_wgrad(const int32_t *rowptr, const int32_t *col, in
   GSAGE_CHECK_LAUNCH();
   hipLaunchKernelGGL(hidden1_wgrad_k, dim3(WG_WAVES), dim3(64), 0, st, (const int2 *)w.desc,
                      (const int *)(w.soff + rows_cap), col, u_rows, grad_agg, grad_x, (const float *)w.params,
-                     w.partial);
+                     w.partial, rows, n_rows, (int)rows_cap);
   GSAGE_CHECK_LAUNCH();
   hipLaunchKernelGGL(wg_reduce1_k, dim3(4, WG_SLICES), dim3(256), 0, st, (const float *)w.partial, w.red);
   GSAGE_CHECK_LAUNCH();
