@@ -486,7 +486,10 @@ sg_rows_gather_k(const int *__restrict__ rowptr, const int *__restrict__ col,
                  const int *__restrict__ rows, const int *__restrict__ n_rows, int64_t cap,
                  int64_t D, float *__restrict__ out) {
   constexpr int G = 64 / LPR;
-  constexpr int NB = 4;
+#ifndef SG_ROWS_NB
+#define SG_ROWS_NB 4
+#endif
+  constexpr int NB = SG_ROWS_NB;
   const int lane = gs_lane();
   const int slot = lane / LPR, sub = lane % LPR;
   int64_t n = *n_rows;
@@ -524,11 +527,14 @@ sg_rows_gather_k(const int *__restrict__ rowptr, const int *__restrict__ col,
         wt[k] = __shfl(wv, j, 64);
         const int rj = __shfl(rv, j, 64);      // (every lane takes part: lane j may itself be past the end)
         ri[k] = valid ? rj : -1;
+        // whole steps past the end (the same for every lane) fetch nothing; within the last step the
         // slots past the end re-read the last term's row (cached) and are answered by no accumulator
-        r[k] = *(const float4 *)(emb + (int64_t)c * D + sub * 4);
+        r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s + k < steps) r[k] = *(const float4 *)(emb + (int64_t)c * D + sub * 4);
       }
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
+        if (s + k >= steps) break;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
           const bool hit = ri[k] == i;          // select the product, not the weight: 0 * inf is NaN
