@@ -72,6 +72,10 @@ def parse_args(argv=None):
     ap.add_argument("--cache-input-aggregation", action="store_true",
                     help="opt-in extra (not the headline): keep mean_j x_j of the constant input "
                          "features across steps instead of recomputing it like the reference")
+    ap.add_argument("--cpu-c4-one-step", action="store_true",
+                    help="CPU leg only (no GPU work, minutes of host time): ONE step of the CPU oracle on "
+                         "the full C4 graph at the bench's batch, SURVEY 8(d)'s last CPU figure; the "
+                         "result is kept in profiles/, the default run does not repeat it")
     return ap.parse_args(argv)
 
 
@@ -343,7 +347,56 @@ def cpu_full_size_configs(K):
                     "cores": used})
         del model, opt, ei, x
     torch.set_num_threads(threads)
+    # C4 in full takes ~30 s a step and ~150 GB of host memory: measured once with
+    # `bench.py --cpu-c4-one-step` on the GPU box's host and kept under profiles/, not repeated here
+    rec = os.path.join(ROOT, "profiles", "r03_cpu_c4_one_step.json")
+    if os.path.exists(rec):
+        with open(rec) as f:
+            r = json.loads(f.read().strip().splitlines()[-1])
+        res.append({"config": "C4: 10M-node/~200M-edge power-law graph, one step at the bench's batch",
+                    "nodes": r["nodes"], "edges": r["edges"], "pairs_per_step": r["pairs_per_step"],
+                    "ms_per_step": r["s_per_step"] * 1e3, "pairs_per_s": r["value"], "steps": r["steps"],
+                    "cores": r["cores"], "recorded": "profiles/r03_cpu_c4_one_step.json (not re-measured by this run)"})
     return res
+
+
+def cpu_c4_one_step(args):
+    """SURVEY 8(d) "C4 one step (expect minutes)": the CPU oracle's training step on the full
+    10 M-node / 200 M-edge graph at the bench's batch (2^20 pairs, K = 5), once, no warm-up.  Far too
+    long for the default run, so it has a flag of its own and its line is committed under profiles/.
+    The oracle materialises PyG's [E, F] message tensors (51 GB at F = 64): expect ~150 GB of host memory."""
+    import threading
+    import torch
+    from graphsage_amd.synth import cooccurrence_batch, memory_features, powerlaw_graph
+    from oracle import sage_oracle as O
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    nodes, deg = WORKLOADS["c4"][0], WORKLOADS["c4"][1]
+    done = threading.Event()
+
+    def heartbeat():                      # a line every 30 s: a silent minutes-long step looks hung
+        t0 = time.perf_counter()
+        while not done.wait(30.0):
+            log(f"cpu C4 step: still running, {time.perf_counter() - t0:.0f} s")
+    threading.Thread(target=heartbeat, daemon=True).start()
+    t0 = time.perf_counter()
+    ei = powerlaw_graph(nodes, deg, seed=42)
+    x = memory_features(nodes, seed=42)
+    batch = cooccurrence_batch(ei, nodes, args.pairs_per_gpu, args.negatives, seed=1001)
+    log(f"cpu C4 step: graph and batch ready after {time.perf_counter() - t0:.0f} s ({ei.size(1)} edges)")
+    torch.manual_seed(0)
+    model = O.OracleGraphSAGE(7, 64, 64, 2, args.dropout).train()
+    opt = O.make_adam(model)
+    t1 = time.perf_counter()
+    stats = O.train_step(model, opt, x, ei, *batch)
+    dt = time.perf_counter() - t1
+    done.set()
+    loss = float(stats[0]) if isinstance(stats, (tuple, list)) else float(stats)
+    print(json.dumps({"metric": "trained co-occurrence pairs/sec (CPU oracle, one full C4 step)",
+                      "value": args.pairs_per_gpu / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+                      "nodes": nodes, "edges": int(ei.size(1)), "pairs_per_step": args.pairs_per_gpu,
+                      "negatives": args.negatives, "s_per_step": dt, "steps": 1, "loss": loss,
+                      "sample": "the whole workload: one step, no warm-up"}), flush=True)
 
 
 # ------------------------------------------------------------------- launch-path self-test
@@ -875,6 +928,9 @@ def main():
     args = parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.cpu_c4_one_step:
+        cpu_c4_one_step(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))       # before any GPU call in this process
     R = Ranks(args)
