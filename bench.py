@@ -482,8 +482,9 @@ def step_anatomy(args, summ, N, E, F, D, B, K, R, Le):
                                  if F == 64 and D == 64 else
                                  [f"gemm_split_k<{D // 64}>", "split_planes_k"],
                                  "layer-2 projection + L2 norm", 8 * F * N + 4 * D * N + 4 * N),
-        f"project_bwd_rows_{F}x{D}": (["bwd64_fused_k<2, true, true>" if os.environ.get("GSAGE_BWD64", "")[:1] != "f"
-                                       else "bwd64_fused_k<2, true, false>", "reduce_slabs_k", "pack_dx_k"],
+        f"project_bwd_rows_{F}x{D}": ([{"f": "bwd64_fused_k<2, true, false>", "d": "bwd64_fused_k<2, true, true>"}.get(
+                                           os.environ.get("GSAGE_BWD64", "")[:1], "bwd64h_rows_k<2>"),
+                                       "reduce_slabs_k", "pack_dx_k", "bwd64h_pack_k"],
                                       "fused layer-2 backward (L2-norm', dX, dW) over the touched rows",
                                       R * (4 * D * 2 + 4 * F * 2) + R * 8 * F + 4 * R),
         f"project_bwd_8x{F}_weights_only": (["dw16_mfma_k", "reduce_dw16_k"],
@@ -688,7 +689,8 @@ def run_training(args, R):
     if hidden == 64 and out_dim == 64 and _ops.RANGE_WORDS and os.environ.get("GSAGE_PROJ64", "")[:1] != "f":
         halves.append("the 64->64 forward projection")
     if any(a["tag"].startswith("project_bwd_rows") for a in anatomy) and os.environ.get("GSAGE_BWD64", "")[:1] != "f":
-        halves.append("the dX half of the fused 64->64 backward")
+        halves.append("the dX half of the fused 64->64 backward" if os.environ.get("GSAGE_BWD64", "")[:1] == "d"
+                      else "the fused 64->64 backward over the touched rows (dX and dW)")
     if any(a["tag"].startswith("hidden1_wgrad") for a in anatomy):
         halves.append("the input layer's weight gradients (one pass over the live edges)")
     if halves:

@@ -1874,6 +1874,263 @@ bwd64_fused_k(const float *__restrict__ g, const float *__restrict__ y,
   if (t < 64) slab[64 * 128 + t] = bsum;
 }
 
+// ---- The row-list backward of a 64 -> 64 layer with BOTH products on the fp16 pipe (round 3, last).
+// bwd64_fused_k<.., HDX> cuts its dpre tile in two fp16 parts as each wave reads it back from LDS --
+// all four waves need all of it, so every value is cut four times -- and keeps dW on fp32 MFMAs
+// (64 cycles each); moving dW to fp16 the same way cost more in cuts and strided LDS reads than its
+// MFMAs had (ablation: 0.61 ms of reads + cuts for 0.15 ms of MFMAs).  Here every value is cut ONCE,
+// by the thread that stages it, and LDS holds fp16 planes only:
+//   Dr  dpre row-major, each row scaled by its own power of two      -> the A operand of dX
+//   Dt  dpre transposed ([column][row pair] words), scaled per 8-row block -> the A operand of dW
+//   At  [agg | x] transposed the same way                            -> the B operand of dW
+// The transposed planes come for free from the cut itself: a thread holds two consecutive rows,
+// and v_cvt_pkrtz of (row 2i, row 2i+1) of one column IS the word of that column's row pair.  dW sums
+// over rows, so rows that meet in one MFMA need one scale: the 8 rows a wave stages are exactly the
+// k = 8 of v_mfma_f32_32x32x8_f16 (no barrier between finding their maximum and cutting them); each
+// block's product lands in a fresh accumulator and is added to the running fp32 sums with its own
+// exact power of two (chains of 3 MFMAs: nothing for the pipe's truncating accumulate to add up).
+// Single LDS stage, two barriers per tile, 38 KB per workgroup.  Anatomy at C4 (4.36 M listed rows, kernel
+// 1.54 ms against 1.68 for bwd64_fused_k<.., HDX>): fetch + cut + planes 0.81 ms (4.5 GB of listed rows:
+// 5.5 TB/s), the dX phase 0.57 ms -- nearly all of it its 2.2 GB of stores, whole 128-byte lines of
+// scattered rows at 3.1 TB/s, which add to the reads instead of hiding under them -- and dW 0.16 ms, of
+// which 0.03 are its 24 MFMAs and the rest the eight accumulator flushes per tile (v_pk_fma_f32).
+// 6.7 GB in 1.54 ms = 4.35 TB/s: what is left is the memory system's mixed read/write rate on rows
+// fetched by number.
+typedef _Float16 p64h_f4 __attribute__((ext_vector_type(4)));
+typedef short p64h_b4 __attribute__((ext_vector_type(4)));
+constexpr int B64H_DRP = 72;   // halves per row of Dr (144 bytes: conflict-free 16-byte row slices)
+constexpr int B64H_TP = 18;    // words per column of Dt / At (16 row pairs + 2: conflict-free 8-byte slices)
+
+__device__ __forceinline__ float p64h_inv_pow2(float s) { return __uint_as_float(0x7F000000u - __float_as_uint(s)); }
+
+template <int MODE>   // 0 = no epilogue, 1 = ReLU(+dropout), 2 = L2 normalisation
+__global__ void __launch_bounds__(256, 3)
+bwd64h_rows_k(const float *__restrict__ g, const float *__restrict__ y, const float *__restrict__ rnorm,
+              const float *__restrict__ agg, const float *__restrict__ x,
+              const float *__restrict__ agg_scale, float inv_keep, float *__restrict__ grad_agg,
+              float *__restrict__ grad_x, float *__restrict__ slabs, const int *__restrict__ rows,
+              const int *__restrict__ n_rows, int64_t rows_cap, unsigned *__restrict__ gmax,
+              const uint16_t *__restrict__ hplanes, const float *__restrict__ hparams) {
+  constexpr int TR = 32;
+  __shared__ __align__(16) uint16_t Dr[2 * TR * B64H_DRP];
+  __shared__ __align__(16) uint32_t Dt[2 * 64 * B64H_TP];
+  __shared__ __align__(16) uint32_t At[2 * 128 * B64H_TP];
+  __shared__ float sc[TR], rsI[TR], ubl[4];
+  __shared__ int rid[TR];
+  __shared__ unsigned gmx[256];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int64_t M = *n_rows;
+  if (M > rows_cap) M = rows_cap;
+  // dX: wave w owns output columns 32w..32w+31 of [grad_agg | grad_x]; B operand of k-step s:
+  // column 32 w + (lane & 31), k = 16 s + 8 (lane >> 5) .. + 7 of both weight planes (bwd64h_pack_k)
+  p64h_f8 bh[4], bl[4];
+  const float inv_sw = hparams[0];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) {
+    const int off = (w * 32 + (lane & 31)) * 64 + 16 * s2 + 8 * (lane >> 5);
+    bh[s2] = __builtin_bit_cast(p64h_f8, *(const p64h_b8 *)(hplanes + off));
+    bl[s2] = __builtin_bit_cast(p64h_f8, *(const p64h_b8 *)(hplanes + 128 * 64 + off));
+  }
+  f32x16 dw0, dw1;   // dW: rows m = dpre column 0..31 / 32..63, columns 32w .. 32w+31 of [agg | x]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; }
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);   // this thread's share of the bias gradient (its 4 columns)
+  gmx[t] = 0u;
+  const int rsub = t >> 4, c4 = (t & 15) * 4;
+  const int wi = rsub;                           // row pair (rows 2 rsub, 2 rsub + 1): word index in Dt / At
+  const int64_t ntiles = (M + TR - 1) / TR;
+  float4 gv[2], yv[2], av[2], xv[2];
+  float rn[2], scv = 1.f;
+  int nid[2] = {0, 0}, cid[2] = {0, 0}, srow = 0, nsrow = 0;
+#define B64H_IDS(ROW0)                                                             \
+  {                                                                                \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                \
+      const int64_t pos = (ROW0) + rsub * 2 + p;                                   \
+      nid[p] = rows[pos < M ? pos : 0];                                            \
+    }                                                                              \
+    if (t < TR) nsrow = rows[(ROW0) + t < M ? (ROW0) + t : 0];                     \
+  }
+#define B64H_FETCH(ROW0)                                                           \
+  {                                                                                \
+    cid[0] = nid[0]; cid[1] = nid[1]; srow = nsrow;                                \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                \
+      const bool in = (ROW0) + rsub * 2 + p < M;                                   \
+      const int64_t row = in ? (int64_t)cid[p] : 0;                                \
+      gv[p] = *(const float4 *)(g + row * 64 + c4);                                \
+      if (MODE != 0) yv[p] = *(const float4 *)(y + row * 64 + c4);                 \
+      if (MODE == 2) rn[p] = rnorm[row];                                           \
+      av[p] = *(const float4 *)(agg + row * 64 + c4);                              \
+      xv[p] = *(const float4 *)(x + row * 64 + c4);                                \
+      if (!in) {                                                                   \
+        gv[p] = make_float4(0.f, 0.f, 0.f, 0.f);                                   \
+        yv[p] = gv[p]; av[p] = gv[p]; xv[p] = gv[p];                               \
+        rn[p] = 0.f;                                                               \
+      }                                                                            \
+    }                                                                              \
+    if (t < TR) scv = (agg_scale && (ROW0) + t < M) ? agg_scale[(int64_t)srow] : 1.f; \
+  }
+  // two values, scaled -> (word of fp16 high parts, word of fp16 low parts), round to zero
+#define B64H_CUT(V0, V1, S, HI, LO)                                                                    \
+  {                                                                                                    \
+    const float v0_ = (V0) * (S), v1_ = (V1) * (S);                                                    \
+    const p64h_f2 h_ = __builtin_bit_cast(p64h_f2, __builtin_amdgcn_cvt_pkrtz(v0_, v1_));              \
+    HI = __builtin_bit_cast(uint32_t, h_);                                                             \
+    LO = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v0_ - (float)h_[0], v1_ - (float)h_[1])); \
+  }
+  const int64_t gstep = gridDim.x;
+  if ((int64_t)blockIdx.x < ntiles) {
+    B64H_IDS((int64_t)blockIdx.x * TR)
+    B64H_FETCH((int64_t)blockIdx.x * TR)
+    if ((int64_t)blockIdx.x + gstep < ntiles) B64H_IDS(((int64_t)blockIdx.x + gstep) * TR)
+  }
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * TR;
+    // ---- the tile's operands, cut once, into the planes
+    {
+      float4 d[2];
+      float md = 0.f, mx = 0.f;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        d[p] = gv[p];
+        if (MODE == 2) {
+          float dot = gv[p].x * yv[p].x + gv[p].y * yv[p].y + gv[p].z * yv[p].z + gv[p].w * yv[p].w;
+          dot = row16_sum(dot);
+          if (rn[p] >= 0.5f / L2_EPS) dot = 0.f;   // clamped norm: dy/dx = I / eps
+          d[p].x = (gv[p].x - yv[p].x * dot) * rn[p]; d[p].y = (gv[p].y - yv[p].y * dot) * rn[p];
+          d[p].z = (gv[p].z - yv[p].z * dot) * rn[p]; d[p].w = (gv[p].w - yv[p].w * dot) * rn[p];
+        } else if (MODE == 1) {
+          d[p].x = yv[p].x > 0.f ? d[p].x * inv_keep : 0.f; d[p].y = yv[p].y > 0.f ? d[p].y * inv_keep : 0.f;
+          d[p].z = yv[p].z > 0.f ? d[p].z * inv_keep : 0.f; d[p].w = yv[p].w > 0.f ? d[p].w * inv_keep : 0.f;
+        }
+        bs.x += d[p].x; bs.y += d[p].y; bs.z += d[p].z; bs.w += d[p].w;
+        const int r = rsub * 2 + p;
+        // the row's largest magnitude (its 64 values sit in 16 consecutive lanes) -> its scale for dX
+        float m = fmaxf(fmaxf(fabsf(d[p].x), fabsf(d[p].y)), fmaxf(fabsf(d[p].z), fabsf(d[p].w)));
+        m = row16_max(m);
+        md = fmaxf(md, m);
+        const float sr = P64H_TOP / p64h_pow2_floor(m, P64H_TOP);   // a power of two (1: nothing usable)
+        if ((t & 15) == 0) rsI[r] = p64h_inv_pow2(sr) * inv_sw;
+        uint2 hq, lq;
+        B64H_CUT(d[p].x, d[p].y, sr, hq.x, lq.x)
+        B64H_CUT(d[p].z, d[p].w, sr, hq.y, lq.y)
+        *(uint2 *)(Dr + r * B64H_DRP + c4) = hq;
+        *(uint2 *)(Dr + TR * B64H_DRP + r * B64H_DRP + c4) = lq;
+        float ma = fmaxf(fmaxf(fmaxf(fabsf(av[p].x), fabsf(av[p].y)), fmaxf(fabsf(av[p].z), fabsf(av[p].w))),
+                         fmaxf(fmaxf(fabsf(xv[p].x), fabsf(xv[p].y)), fmaxf(fabsf(xv[p].z), fabsf(xv[p].w))));
+        mx = fmaxf(mx, row16_max(ma));
+      }
+      // the wave's 8 rows = one k-block of dW: their common scales (lanes 16 apart hold other row pairs)
+      md = fmaxf(md, __shfl_xor(md, 16, 64)); md = fmaxf(md, __shfl_xor(md, 32, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float sd = P64H_TOP / p64h_pow2_floor(md, P64H_TOP), sx = P64H_TOP / p64h_pow2_floor(mx, P64H_TOP);
+      if (lane == 0) ubl[w] = p64h_inv_pow2(sd) * p64h_inv_pow2(sx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t hi, lo;
+        B64H_CUT(f4c(d[0], i), f4c(d[1], i), sd, hi, lo)
+        Dt[(c4 + i) * B64H_TP + wi] = hi;
+        Dt[64 * B64H_TP + (c4 + i) * B64H_TP + wi] = lo;
+        B64H_CUT(f4c(av[0], i), f4c(av[1], i), sx, hi, lo)
+        At[(c4 + i) * B64H_TP + wi] = hi;
+        At[128 * B64H_TP + (c4 + i) * B64H_TP + wi] = lo;
+        B64H_CUT(f4c(xv[0], i), f4c(xv[1], i), sx, hi, lo)
+        At[(64 + c4 + i) * B64H_TP + wi] = hi;
+        At[128 * B64H_TP + (64 + c4 + i) * B64H_TP + wi] = lo;
+      }
+      if (t < TR) {
+        sc[t] = scv;
+        rid[t] = srow;
+      }
+    }
+    __syncthreads();
+    if (tile + gstep < ntiles) {
+      B64H_FETCH((tile + gstep) * TR)
+      if (tile + 2 * gstep < ntiles) B64H_IDS((tile + 2 * gstep) * TR)
+    }
+    // ---- dX = dpre . [W_l | W_r]: row lane & 31, k = 16 s + 8 (lane >> 5) .. + 7
+    {
+      f32x16 a0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a0[r] = 0.f;
+      const uint16_t *dr = Dr + (lane & 31) * B64H_DRP + 8 * (lane >> 5);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const p64h_f8 ah = __builtin_bit_cast(p64h_f8, *(const p64h_b8 *)(dr + 16 * s2));
+        const p64h_f8 al = __builtin_bit_cast(p64h_f8, *(const p64h_b8 *)(dr + TR * B64H_DRP + 16 * s2));
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s2], a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s2], a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s2], a0, 0, 0, 0);
+      }
+      float *dst = (w < 2 ? grad_agg : grad_x) + (w & 1) * 32 + (lane & 31);
+      unsigned gamx = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int64_t grow = (int64_t)rid[lr];
+        const float s = (w < 2 ? sc[lr] : 1.f) * rsI[lr];
+        if (row0 + lr < M) {
+          const float v = a0[r] * s;
+          dst[grow * 64] = v;
+          gamx = max(gamx, __float_as_uint(v) & 0x7FFFFFFFu);
+        }
+      }
+      if (gmax) gmx[t] = max(gmx[t], gamx);
+    }
+    // ---- dW[m = dpre column][n = column 32 w + .. of [agg | x]] += block by block (8 rows each)
+    {
+      const uint32_t *atp = At + (w * 32 + (lane & 31)) * B64H_TP + 2 * (lane >> 5);
+      const uint32_t *dtp = Dt + (lane & 31) * B64H_TP + 2 * (lane >> 5);
+      f32x16 zero;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll 1     // (unrolled, the eight independent products are scheduled side by side: 128 registers)
+      for (int b = 0; b < 4; ++b) {
+        const float un = ubl[b];
+        f32x16 unv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) unv[r] = un;
+        const p64h_f4 xh = __builtin_bit_cast(p64h_f4, *(const p64h_b4 *)(atp + 4 * b));
+        const p64h_f4 xl = __builtin_bit_cast(p64h_f4, *(const p64h_b4 *)(atp + 128 * B64H_TP + 4 * b));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const p64h_f4 dh = __builtin_bit_cast(p64h_f4, *(const p64h_b4 *)(dtp + 32 * h * B64H_TP + 4 * b));
+          const p64h_f4 dl = __builtin_bit_cast(p64h_f4, *(const p64h_b4 *)(dtp + (64 + 32 * h) * B64H_TP + 4 * b));
+          f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x8f16(dl, xh, zero, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x8f16(dh, xl, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x8f16(dh, xh, acc, 0, 0, 0);
+          // (whole-vector form: v_pk_fma_f32, two sums per instruction)
+          if (h == 0) dw0 = __builtin_elementwise_fma(acc, unv, dw0);
+          else dw1 = __builtin_elementwise_fma(acc, unv, dw1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();     // every wave is done with the planes: the next tile may overwrite them
+  }
+  if (gmax) amax_publish(gmx[t], gmax);
+#undef B64H_IDS
+#undef B64H_FETCH
+#undef B64H_CUT
+  float *slab = slabs + (int64_t)blockIdx.x * (64 * 128 + 64);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mrow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int ncol = w * 32 + (lane & 31);
+    slab[mrow * 128 + ncol] = dw0[r];
+    slab[(32 + mrow) * 128 + ncol] = dw1[r];
+  }
+  // bias gradient: the 16 threads that staged a column quad, summed in a fixed order
+  float *bred = (float *)At;
+  *(float4 *)(bred + rsub * 64 + c4) = bs;
+  __syncthreads();
+  if (t < 64) {
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += bred[k * 64 + t];
+    slab[64 * 128 + t] = sum;
+  }
+}
+
 constexpr int S64_GRID = 256 * 3;   // persistent workgroups (3 per CU fit LDS)
 constexpr int S64_BWD_GRID = 256 * 3;
 
@@ -2434,11 +2691,12 @@ static bool proj64_half_mode() {
   }();
   return v;
 }
-// GSAGE_BWD64=f32 keeps the dX half of the fused 64 -> 64 backward (row-list form) on fp32 MFMAs
-static bool bwd64_half_mode() {
-  static const bool v = [] {
+// the fused 64 -> 64 backward, row-list form: GSAGE_BWD64=f32 keeps it on fp32 MFMAs, =dx puts only
+// its dX half on the fp16 pipe (bwd64_fused_k<.., HDX>); default: dX and dW both (bwd64h_rows_k)
+static int bwd64_half_mode() {
+  static const int v = [] {
     const char *e = getenv("GSAGE_BWD64");
-    return !(e && e[0] == 'f');
+    return (e && e[0] == 'f') ? 0 : (e && e[0] == 'd') ? 1 : 2;
   }();
   return v;
 }
@@ -2753,9 +3011,16 @@ static int project_bwd_impl(const float *grad_out, const float *out, const float
                  : epilogue == GSAGE_EPI_L2NORM ? bwd64_fused_k<2, true, true> : bwd64_fused_k<1, true, true>;
         }
       }
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x,
-                         wp, agg_scale, N, ik, grad_agg, grad_x, slabs, nz_mask, live_rows, n_live,
-                         live_cap, gmax, hplanes, hparams);
+      if (live_rows && bwd64_half_mode() == 2) {
+        auto kh = epilogue == GSAGE_EPI_NONE ? bwd64h_rows_k<0>
+                  : epilogue == GSAGE_EPI_L2NORM ? bwd64h_rows_k<2> : bwd64h_rows_k<1>;
+        hipLaunchKernelGGL(kh, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x, agg_scale, ik,
+                           grad_agg, grad_x, slabs, live_rows, n_live, live_cap, gmax, hplanes, hparams);
+      } else {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, grad_out, out, rnorm, agg, x,
+                           wp, agg_scale, N, ik, grad_agg, grad_x, slabs, nz_mask, live_rows, n_live,
+                           live_cap, gmax, hplanes, hparams);
+      }
       GSAGE_CHECK_LAUNCH();
       hipLaunchKernelGGL(reduce_slabs_k, dim3((unsigned)((2 * Fi * Fo + Fo + 63) / 64)), dim3(256), 0,
                          st, slabs, grid, fi, fo, grad_w_l, grad_w_r, grad_b);

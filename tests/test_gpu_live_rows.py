@@ -264,3 +264,24 @@ def test_full_size_c4_backward_with_and_without_the_row_list():
         assert scale > 0 and bool(torch.isfinite(a).all())
         # float atomics in the loss backward make the last bits run-dependent in both runs
         assert float((a - d).abs().max()) <= 1e-5 * scale, name
+
+
+def test_row_list_backward_in_its_other_arithmetic_modes():
+    """gsage_project_bwd_rows has three forms: everything on fp32 MFMAs (GSAGE_BWD64=f32), the dX half on
+    the fp16 pipe (=dx, bwd64_fused_k<.., HDX>) and, the default, dX and dW both (bwd64h_rows_k).  The
+    library reads the switch once, so the two that are not the default run this file's row-list cases
+    in a child process each."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("GSAGE_BWD64"):
+        pytest.skip("already inside the forced run")
+    here = os.path.dirname(os.path.abspath(__file__))
+    for mode in ("f32", "dx"):
+        env = dict(os.environ, GSAGE_BWD64=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                            os.path.join(here, "test_gpu_live_rows.py"), "-k",
+                            "test_project_bwd_rows_equals_dense_backward or test_backward_through_model"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, f"GSAGE_BWD64={mode}:\n{r.stdout[-3000:]}\n{r.stderr[-1000:]}"
+        assert " passed" in r.stdout
