@@ -265,6 +265,47 @@ def test_full_size_c4_backward_with_and_without_the_row_list():
         # float atomics in the loss backward make the last bits run-dependent in both runs
         assert float((a - d).abs().max()) <= 1e-5 * scale, name
 
+@pytest.mark.parametrize("kind", ["independent", "adverse"])
+def test_row_list_backward_on_rows_far_apart(kind):
+    """The fp16 forms scale dX per gradient row and dW per block of 8 listed rows.  Rows whose gradient and
+    operand magnitudes spread independently over 2^+-24 must not cost accuracy, and neither may the adverse
+    pattern -- large gradients on the rows with the small operands, alternating inside every block -- while
+    the two factors lie 2^16 apart (the limit INTEGRATION.md states).  The reference computes this chain in
+    fp32 (autograd of graphsage.py:138); bar: 1e-5 of the largest gradient, against float64."""
+    from graphsage_amd import _lib, ops
+    n = 60_000
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(17)
+    if kind == "independent":
+        def mk():
+            mag = torch.exp2((torch.rand(n, 1, device=dev, generator=g) * 2 - 1) * 24)
+            return torch.randn(n, 64, device=dev, generator=g) * mag
+        go, agg, x = mk(), mk(), mk()
+        rows = torch.nonzero(torch.rand(n, device=dev, generator=g) < 0.45).flatten().int()
+    else:
+        alt = (torch.arange(n, device=dev) & 1).float().mul(2).sub(1).unsqueeze(1)
+        up, down = torch.exp2(alt * 8), torch.exp2(-alt * 8)
+        go = torch.randn(n, 64, device=dev, generator=g) * up
+        agg = torch.randn(n, 64, device=dev, generator=g) * down
+        x = torch.randn(n, 64, device=dev, generator=g) * down
+        rows = torch.arange(n, device=dev, dtype=torch.int32)
+    w_l = torch.randn(64, 64, device=dev, generator=g) / 8
+    w_r = torch.randn(64, 64, device=dev, generator=g) / 8
+    cap = rows.numel()
+    live = ops.LiveRows(None, rows, torch.tensor([cap], dtype=torch.int32, device=dev), cap, 0, n)
+    ga, gx, gwl, gb, gwr = ops.project_bwd_rows(go, None, None, agg, x, w_l, w_r, torch.ones(n, device=dev),
+                                                _lib.EPI_NONE, 0.0, live)
+    r = rows.long()
+    d = go[r].double()
+    for name, got, want in (("grad_w_l", gwl, d.t() @ agg[r].double()), ("grad_b", gb, d.sum(0)),
+                            ("grad_w_r", gwr, d.t() @ x[r].double())):
+        err = float((got.double() - want).abs().max()) / float(want.abs().max())
+        assert err <= 1e-5, (kind, name, err)
+    for name, got, w in (("grad_agg", ga, w_l), ("grad_x", gx, w_r)):     # every row against its own largest
+        want = d @ w.double()
+        rel = (got[r].double() - want).abs().max(1).values / want.abs().max(1).values.clamp_min(1e-300)
+        assert float(rel.max()) <= 1e-5, (kind, name, float(rel.max()))
+
 
 def test_row_list_backward_in_its_other_arithmetic_modes():
     """gsage_project_bwd_rows has three forms: everything on fp32 MFMAs (GSAGE_BWD64=f32), the dX half on
