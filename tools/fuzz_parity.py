@@ -5,7 +5,8 @@ repeated ids, the recompute gather forced on or left to its size switch.  Embedd
 parameter gradient at the parity bar (1e-5, floors as in tests/test_gpu_model.py) against the oracle run in
 float64; where fp32 cannot reach that (ill-conditioned sums), within 8x of the fp32 oracle's own error (the fp16
 two-part kernels carry 22 significant bits per operand against fp32's 24).
-    PYTHONPATH=.:tests python tools/fuzz_parity.py [cases = 200] [first seed = 0]
+    PYTHONPATH=.:tests python tools/fuzz_parity.py [cases = 200] [first seed = 0] [eval]
+(`eval`: the inference forward instead -- eval mode, no_grad, the column-blocked layout forced on or off)
 Prints one line per case; stops at the first failure with the seed that reproduces it."""
 import copy
 import os
@@ -134,15 +135,54 @@ def one_case(seed):
     return tag + ("  [" + "; ".join(notes) + "]" if notes else "")
 
 
+def one_eval_case(seed):
+    """Inference (encoder.py:181-185: eval, no_grad): the column-blocked layout of the wide models and the
+    recompute gather forced on or off; embeddings against the oracle in float64."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
+    hidden = (64, 128, 256, 256)[r(0, 3)]
+    layers = r(1, 3)
+    n = r(1, 2500) if hidden == 64 else r(1, 1200)
+    ei = random_graph(g, n)
+    x = torch.randn(n, 7, generator=g) * float(10.0 ** r(-3, 3))
+    blocked, force = r(0, 1), r(0, 1)
+    ops.BLOCKED_MIN_BYTES = 0 if blocked else (1 << 62)
+    ops.HIDDEN1_MIN_BYTES = 0 if force else (1 << 62)
+    cfg = dict(in_channels=7, hidden_channels=hidden, out_channels=hidden, num_layers=layers, dropout=0.3)
+    torch.manual_seed(seed)
+    ref = O.OracleGraphSAGE(**cfg).eval()
+    m = GraphSAGE(**cfg)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        emb = m(x.cuda(), ei.cuda()).cpu()
+        o32 = ref(x, ei)
+        exact = copy.deepcopy(ref).double()(x.double(), ei)
+    tag = (f"eval seed {seed}: n={n} E={ei.size(1)} hidden={hidden} layers={layers} "
+           f"blocked={'forced' if blocked else 'off'} recompute={'forced' if force else 'off'}")
+    note = ""
+    try:
+        assert_close(emb, exact, what=tag)
+    except AssertionError:
+        ours, theirs = float((emb.double() - exact).abs().max()), float((o32.double() - exact).abs().max())
+        if ours > 8 * theirs:
+            print(f"{tag}: our error {ours:.2e}, the fp32 oracle's {theirs:.2e}", flush=True)
+            raise
+        WORST[0] = max(WORST[0], ours / max(theirs, 1e-300))
+        note = f"  [ill-conditioned: our error {ours:.1e}, the fp32 oracle's {theirs:.1e}]"
+    return tag + note
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    keep_default = ops.HIDDEN1_MIN_BYTES
+    keep_default = (ops.HIDDEN1_MIN_BYTES, ops.BLOCKED_MIN_BYTES)
+    case = one_eval_case if len(sys.argv) > 3 and sys.argv[3] == "eval" else one_case
     try:
         for s in range(first, first + cases):
-            print(one_case(s) + ": ok", flush=True)
+            print(case(s) + ": ok", flush=True)
     finally:
-        ops.HIDDEN1_MIN_BYTES = keep_default
+        ops.HIDDEN1_MIN_BYTES, ops.BLOCKED_MIN_BYTES = keep_default
     print(f"{cases} cases ok; recompute gathers {ops.HIDDEN1_STATS['used']}, hand-overs to gsage_hidden1_wgrad "
           f"{ops.WGRAD_STATS['used']}, row-list backwards {ops.LIVE_STATS['used']}; worst error ratio to the fp32 "
           f"oracle among ill-conditioned values {WORST[0]:.1f}", flush=True)
