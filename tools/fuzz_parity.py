@@ -173,11 +173,54 @@ def one_eval_case(seed):
     return tag + note
 
 
+def one_loss_case(seed):
+    """SkipGramLoss alone (loss.py:97-136, 161-193) on arbitrary embedding widths, batch shapes and scale
+    factors: loss, the seven details and d loss / d embeddings against float64 autograd."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
+    d = (64, 64, 128, 256, r(1, 300), r(1, 40))[r(0, 5)]
+    n, b, k = r(1, 5000), r(1, 3000), r(1, 9)
+    scale = (5.0, 5.0, 1.0, 0.25, 20.0)[r(0, 4)]
+    emb = torch.randn(n, d, generator=g)
+    if r(0, 1):
+        emb = torch.nn.functional.normalize(emb, dim=1)
+    t = torch.randint(0, n, (b,), generator=g)
+    c = torch.randint(0, n, (b,), generator=g)
+    neg = torch.randint(0, n, (b, k), generator=g)
+    if r(0, 3) == 0:
+        t[:] = t[0]
+    e_gpu = emb.cuda().requires_grad_(True)
+    loss, det = SkipGramLoss(scale_factor=scale).forward_with_details(e_gpu, t.cuda(), c.cuda(), neg.cuda())
+    loss.backward()
+    e64 = emb.double().requires_grad_(True)
+    want, wdet = O.skipgram_loss_with_details(e64, t, c, neg, scale)
+    want.backward()
+    tag = f"loss seed {seed}: n={n} D={d} B={b} K={k} scale={scale}"
+    assert abs(float(loss) - float(want)) <= 1e-5 * abs(float(want)) + 1e-7, (tag, float(loss), float(want))
+    for key, v in wdet.items():
+        assert abs(det[key] - v) <= 1e-5 * abs(v) + 2e-6, (tag, key, det[key], v)
+    note = ""
+    try:
+        assert_close(e_gpu.grad.cpu(), e64.grad, rtol=1e-5, floor=2e-6, what=tag + " d emb")
+    except AssertionError:
+        e32 = emb.clone().requires_grad_(True)
+        O.skipgram_loss(e32, t, c, neg, scale).backward()
+        ours = float((e_gpu.grad.cpu().double() - e64.grad).abs().max())
+        theirs = float((e32.grad.double() - e64.grad).abs().max())
+        if ours > 8 * theirs:
+            print(f"{tag} d emb: our error {ours:.2e}, the fp32 oracle's {theirs:.2e}", flush=True)
+            raise
+        WORST[0] = max(WORST[0], ours / max(theirs, 1e-300))
+        note = f"  [d emb ill-conditioned: our error {ours:.1e}, the fp32 oracle's {theirs:.1e}]"
+    return tag + note
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     keep_default = (ops.HIDDEN1_MIN_BYTES, ops.BLOCKED_MIN_BYTES)
-    case = one_eval_case if len(sys.argv) > 3 and sys.argv[3] == "eval" else one_case
+    mode = sys.argv[3] if len(sys.argv) > 3 else "train"
+    case = {"eval": one_eval_case, "loss": one_loss_case}.get(mode, one_case)
     try:
         for s in range(first, first + cases):
             print(case(s) + ": ok", flush=True)
