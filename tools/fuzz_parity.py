@@ -251,12 +251,45 @@ def one_dropout_case(seed):
     return tag
 
 
+def one_graph_case(seed):
+    """K1 and K2/K7 on their own: the CSR of a random multigraph in both orientations bit for bit against
+    bincount + stable argsort (the order PyG's scatter sums a row's messages in), 1 / max(deg, 1), and the
+    mean aggregation and its transposed backward for a random width against float64."""
+    from graphsage_amd import default_cache
+    g = torch.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
+    n = r(1, 6000)
+    ei = random_graph(g, n)
+    f = (8, 64, 128, 256, 64, r(1, 40) * 4, r(1, 70))[r(0, 6)]
+    gr = default_cache().get(ei.cuda(), n)
+    tag = f"graph seed {seed}: n={n} E={ei.size(1)} F={f}"
+    for key, other, rp, cl in ((1, 0, gr.rowptr, gr.col), (0, 1, gr.rowptr_t, gr.col_t)):
+        deg = torch.bincount(ei[key], minlength=n)
+        want_rp = torch.cat([torch.zeros(1, dtype=torch.int64), deg.cumsum(0)])
+        order = torch.sort(ei[key], stable=True).indices
+        assert torch.equal(rp.cpu().long(), want_rp), tag + " rowptr"
+        assert torch.equal(cl.cpu().long(), ei[other][order]), tag + " col"
+    deg_in = torch.bincount(ei[1], minlength=n)
+    assert torch.equal(gr.inv_deg.cpu(), (1.0 / deg_in.clamp(min=1).float())), tag + " inv_deg"
+    x = torch.randn(n, f, generator=g)
+    got = ops.aggregate_mean(gr, x.cuda()).cpu()
+    want = torch.zeros(n, f, dtype=torch.float64).index_add_(0, ei[1], x.double()[ei[0]]) / \
+        deg_in.clamp(min=1).double()[:, None]
+    assert_close(got, want, what=tag + " mean aggregation")
+    go = torch.randn(n, f, generator=g)
+    gb = ops.aggregate_mean_bwd(gr, go.cuda()).cpu()
+    wb = torch.zeros(n, f, dtype=torch.float64).index_add_(
+        0, ei[0], (go.double() / deg_in.clamp(min=1).double()[:, None])[ei[1]])
+    assert_close(gb, wb, what=tag + " transposed gather")
+    return tag
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     keep_default = (ops.HIDDEN1_MIN_BYTES, ops.BLOCKED_MIN_BYTES)
     mode = sys.argv[3] if len(sys.argv) > 3 else "train"
-    case = {"eval": one_eval_case, "loss": one_loss_case, "dropout": one_dropout_case}.get(mode, one_case)
+    case = {"eval": one_eval_case, "loss": one_loss_case, "dropout": one_dropout_case, "graph": one_graph_case}.get(mode, one_case)
     try:
         for s in range(first, first + cases):
             print(case(s) + ": ok", flush=True)
