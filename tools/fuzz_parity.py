@@ -22,6 +22,7 @@ from util import assert_close  # noqa: E402
 from graphsage_amd import GraphSAGE, SkipGramLoss, ops  # noqa: E402
 
 
+SCALE = int(os.environ.get("FUZZ_NODE_SCALE", "1"))       # node counts of the `train` mode times this
 WORST = [0.0]        # largest (our error / the fp32 oracle's error) among the ill-conditioned values
 
 
@@ -50,10 +51,10 @@ def one_case(seed):
     hidden = (64, 64, 64, 128, 256)[r(0, 4)]
     layers = (2, 2, 2, 1, 3)[r(0, 4)] if hidden == 64 else (2, 3)[r(0, 1)]
     p = (0.0, 0.3, 0.3, 0.5)[r(0, 3)]
-    n = r(1, 3000) if hidden == 64 else r(1, 900)
+    n = (r(1, 3000) if hidden == 64 else r(1, 900)) * SCALE
     ei = random_graph(g, n)
     x = torch.randn(n, 7, generator=g) * float(10.0 ** r(-3, 3))
-    b, k = r(1, 600), r(1, 7)
+    b, k = r(1, 600) * SCALE, r(1, 7)
     t = torch.randint(0, n, (b,), generator=g)
     c = torch.randint(0, n, (b,), generator=g)
     neg = torch.randint(0, n, (b, k), generator=g)
