@@ -369,12 +369,55 @@ def one_step_case(seed):
         (f"; on a ReLU kink: {', '.join(kinks[:3])}" if kinks else "") + ")"
 
 
+def one_feeder_case(seed):
+    """The feeder either side of the path, integer work, bit for bit: the pair list of ragged walks (order
+    included) and its per-walk index against the oracle's restatement of pair_sampler.py:56-86; the alias
+    tables of a random multigraph against the oracle's restatement of negative_sampler.py:76-141, and the
+    kernel's draws against the host mirror of its counter hash and the reference's where() rule."""
+    import numpy as np
+    from graphsage_amd import CooccurrencePairSampler, DegreeBiasedNegativeSampler, rng
+    g = torch.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
+    w_, l_, window = r(1, 300), r(1, 90), r(1, 15)
+    lengths = torch.randint(1, l_ + 1, (w_,), generator=g, dtype=torch.int32)
+    walks = torch.randint(0, 5000, (w_, l_), generator=g, dtype=torch.int32)
+    for i in range(w_):
+        walks[i, lengths[i]:] = -1
+    lists = [walks[i, :lengths[i]].tolist() for i in range(w_)]
+    want = O.extract_pairs(lists, window)
+    ps = CooccurrencePairSampler(window)
+    t, c = ps.extract_pairs_tensor(walks.cuda(), lengths.cuda())
+    tag = f"feeder seed {seed}: walks {w_} x {l_}, window {window}, {len(want)} pairs"
+    assert t.numel() == len(want), tag
+    if want:
+        assert torch.stack([t, c], 1).cpu().tolist() == [list(p_) for p_ in want], tag + " pair list"
+    off = ps.index(walks.cuda(), lengths.cuda()).cpu().tolist()
+    assert off[0] == 0 and off[-1] == len(want), tag + " index"
+    n = r(1, 4000)
+    ei = random_graph(g, n)
+    if ei.size(1) == 0:
+        return tag + "; no edges"
+    smp = DegreeBiasedNegativeSampler(ei.cuda(), n, device=torch.device("cuda"))
+    probs, prob_table, alias = O.alias_table(ei, n)
+    assert torch.equal(smp.probs.cpu(), probs), tag + " probs"
+    assert torch.equal(smp.prob_table.cpu(), prob_table) and torch.equal(smp.alias.cpu(), alias), tag + " alias tables"
+    kseed = (r(0, (1 << 31) - 1) << 31) ^ r(0, (1 << 31) - 1)
+    smp.reseed(kseed)
+    first = (1 << r(0, 34)) - 1 if r(0, 2) == 0 else 0
+    smp._draws = first
+    b, k = r(1, 700), r(1, 9)
+    got = smp.sample(b, k).cpu().numpy()
+    wantd = rng.alias_sample(prob_table.numpy(), alias.numpy(), kseed, first, b * k).reshape(b, k)
+    assert np.array_equal(got, wantd), tag + f" draws (n={n}, first counter {first})"
+    return tag + f"; sampler n={n} E={ei.size(1)} {b} x {k} draws from counter {first}"
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     keep_default = (ops.HIDDEN1_MIN_BYTES, ops.BLOCKED_MIN_BYTES)
     mode = sys.argv[3] if len(sys.argv) > 3 else "train"
-    case = {"eval": one_eval_case, "loss": one_loss_case, "dropout": one_dropout_case, "graph": one_graph_case, "step": one_step_case}.get(mode, one_case)
+    case = {"eval": one_eval_case, "loss": one_loss_case, "dropout": one_dropout_case, "graph": one_graph_case, "step": one_step_case, "feeder": one_feeder_case}.get(mode, one_case)
     try:
         for s in range(first, first + cases):
             print(case(s) + ": ok", flush=True)
