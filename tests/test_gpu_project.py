@@ -115,6 +115,33 @@ def test_inkernel_dropout_matches_host_mirror():
         assert abs(frac - (1 - p)) < 0.02
 
 
+@pytest.mark.parametrize("extra", [0, 512])
+def test_inkernel_dropout_at_the_32_bit_element_index_boundary(extra):
+    """The input layer's kernel draws its masks four at a time on 32-bit element indices while every index of
+    the launch fits (N x Fo <= 2^32) and on 64-bit ones beyond: 2^24 rows x 256 columns is the last launch of
+    the first kind, 512 rows more the first of the second.  Rows at both ends of the table against
+    relu(pre) x mask / (1 - p) with the host mirror's mask at the same 64-bit indices (graphsage.py:134-135)."""
+    from graphsage_amd.ops import project_fwd
+    from graphsage_amd.rng import dropout_keep_mask_range
+    n, fo, p, seed = (1 << 24) + extra, 256, 0.3, 0xFEDC_BA98_7654_3211
+    g = torch.Generator(device="cuda").manual_seed(3)
+    agg = torch.rand(n, 8, device="cuda", generator=g)
+    x = torch.rand(n, 8, device="cuda", generator=g)
+    agg[:, 7] = 0
+    x[:, 7] = 0
+    w_l = torch.randn(fo, 8, device="cuda", generator=g) / 3
+    w_r = torch.randn(fo, 8, device="cuda", generator=g) / 3
+    b = torch.randn(fo, device="cuda", generator=g)
+    out, _ = project_fwd(agg, x, w_l, b, w_r, epilogue=_lib.EPI_RELU_DROPOUT, seed=seed, p=p)
+    for first, count in ((0, 300), ((1 << 23) - 100, 200), (n - 700, 700)):
+        rows = slice(first, first + count)
+        pre = agg[rows].double() @ w_l.double().T + b.double() + x[rows].double() @ w_r.double().T
+        keep = torch.from_numpy(dropout_keep_mask_range(seed, first * fo, count * fo, p)).view(count, fo)
+        want = torch.relu(pre).cpu() * keep.double() / (1 - p)
+        assert_close(out[rows].cpu(), want, what=f"rows {first}..{first + count}")
+    del out
+
+
 def test_weight_grads_bitwise_reproducible():
     from graphsage_amd.ops import project_bwd, project_fwd
     n, fi, fo = 5000, 64, 64
