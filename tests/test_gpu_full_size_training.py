@@ -282,3 +282,52 @@ def test_training_recompute_when_the_forward_kernel_left_no_sign_bits(monkeypatc
         assert_close(res[0][0], other[0], what="embeddings")
         for a, b in zip(res[0][1], other[1]):
             assert_close(a, b, what="gradient")
+
+
+def test_row_table_at_the_top_of_its_32_bit_offsets(monkeypatch):
+    """The recompute gather and gsage_hidden1_wgrad address the 64-byte rows u[j] by 32-bit byte offsets, which
+    is why they take graphs of fewer than 2^26 nodes.  A graph of 2^26 - 8 nodes whose few edges and pairs sit
+    at both ends of the id range: embeddings of the named rows and all six parameter gradients with the
+    recompute gather and the hand-over of the input layer's weight gradients on, against the plain gather and
+    the transposed-gather backward (64-bit addressing throughout) on the same dropout seeds.  The reference
+    semantics of both are graphsage.py:132-138 and autograd of it."""
+    from graphsage_amd import GraphSAGE, SkipGramLoss, ops
+    dev = torch.device("cuda")
+    n = (1 << 26) - 8
+    g = torch.Generator(device=dev).manual_seed(11)
+    top = lambda k: n - 1 - torch.randint(0, 6000, (k,), device=dev, generator=g)        # noqa: E731
+    low = lambda k: torch.randint(0, 6000, (k,), device=dev, generator=g)                # noqa: E731
+    mid = lambda k: (n // 2) + torch.randint(0, 6000, (k,), device=dev, generator=g)     # noqa: E731
+    dst = torch.cat([top(3000), low(3000), mid(3000)]).repeat_interleave(12)
+    src = torch.cat([top(36000), low(36000), top(18000), mid(18000)])[torch.randperm(108000, device=dev, generator=g)]
+    ei = torch.stack([src, dst])
+    x = torch.rand(n, 7, device=dev, generator=g)
+    b = 2000
+    t = torch.cat([top(b // 2), low(b // 2)])
+    c = torch.cat([low(b // 2), top(b // 2)])
+    neg = torch.cat([top(b * 2), mid(b), low(b * 2)]).view(b, 5)
+    named = torch.unique(torch.cat([t, c, neg.flatten()]))
+    results = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, "HIDDEN1_MIN_BYTES", 0 if on else (1 << 62))
+        monkeypatch.setattr(ops, "HIDDEN1_WGRAD", on)
+        torch.manual_seed(0)
+        m = GraphSAGE(7, 64, 64, 2, P).to(dev).train()
+        m.set_dropout_stream(1234567, 0)
+        used = (ops.HIDDEN1_STATS["used"], ops.WGRAD_STATS["used"])
+        emb = m(x, ei)
+        loss = SkipGramLoss()(emb, t, c, neg)
+        loss.backward()
+        if on:
+            assert ops.HIDDEN1_STATS["used"] == used[0] + 1 and ops.WGRAD_STATS["used"] == used[1] + 1
+        else:
+            assert ops.HIDDEN1_STATS["used"] == used[0] and ops.WGRAD_STATS["used"] == used[1]
+        results.append((emb.detach()[named].cpu(), float(loss.detach()), [p.grad.detach().cpu().clone() for p in m.parameters()]))
+        del emb, loss, m
+        torch.cuda.empty_cache()
+    (e1, l1, g1), (e0, l0, g0) = results
+    scale = float(e0.abs().max())
+    assert float((e1 - e0).abs().max()) <= 1e-5 * scale
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    for a, w in zip(g1, g0):
+        assert float((a - w).abs().max()) <= 2e-5 * float(w.abs().max()) + 1e-12
