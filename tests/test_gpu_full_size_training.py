@@ -284,7 +284,7 @@ def test_training_recompute_when_the_forward_kernel_left_no_sign_bits(monkeypatc
             assert_close(a, b, what="gradient")
 
 
-@pytest.mark.parametrize("hidden,n", [(64, (1 << 26) - 8), (128, (1 << 25) - 8)])
+@pytest.mark.parametrize("hidden,n", [(64, (1 << 26) - 8), (128, (1 << 25) - 8), (64, (1 << 26) + 8)])
 def test_row_table_at_the_top_of_its_32_bit_offsets(monkeypatch, hidden, n):
     """The recompute gather and gsage_hidden1_wgrad address the 64-byte rows u[j] by 32-bit byte offsets, which
     is why they take graphs of fewer than 2^26 nodes.  A graph of 2^26 - 8 nodes whose few edges and pairs sit
@@ -292,8 +292,10 @@ def test_row_table_at_the_top_of_its_32_bit_offsets(monkeypatch, hidden, n):
     recompute gather and the hand-over of the input layer's weight gradients on, against the plain gather and
     the transposed-gather backward (64-bit addressing throughout) on the same dropout seeds.  128 columns wide
     the rows take 128 bytes in training (the further column groups' masks ride behind them) and the limit is
-    2^25 nodes; there is no hand-over at that width.  The reference semantics of both are
-    graphsage.py:132-138 and autograd of it."""
+    2^25 nodes; there is no hand-over at that width.  Third case: 8 nodes PAST the limit, where both must step
+    aside by themselves (plain gather, row-list backward with the masked transposed gather) and the result is
+    compared with the dense backward.  The reference semantics of all of it are graphsage.py:132-138 and
+    autograd of it."""
     from graphsage_amd import GraphSAGE, SkipGramLoss, ops
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(11)
@@ -313,16 +315,20 @@ def test_row_table_at_the_top_of_its_32_bit_offsets(monkeypatch, hidden, n):
     for on in (True, False):
         monkeypatch.setattr(ops, "HIDDEN1_MIN_BYTES", 0 if on else (1 << 62))
         monkeypatch.setattr(ops, "HIDDEN1_WGRAD", on)
+        monkeypatch.setattr(ops, "SKIP_ZERO_ROWS", on)
         torch.manual_seed(0)
         m = GraphSAGE(7, hidden, hidden, 2, P).to(dev).train()
         m.set_dropout_stream(1234567, 0)
-        used = (ops.HIDDEN1_STATS["used"], ops.WGRAD_STATS["used"])
+        used = (ops.HIDDEN1_STATS["used"], ops.WGRAD_STATS["used"], ops.LIVE_STATS["used"])
         emb = m(x, ei)
         loss = SkipGramLoss()(emb, t, c, neg)
         loss.backward()
+        inside = n < (1 << 26) // (hidden // 64)
         if on:
-            assert ops.HIDDEN1_STATS["used"] == used[0] + 1
-            assert ops.WGRAD_STATS["used"] == used[1] + (1 if hidden == 64 else 0)
+            assert ops.HIDDEN1_STATS["used"] == used[0] + (1 if inside else 0)
+            assert ops.WGRAD_STATS["used"] == used[1] + (1 if hidden == 64 and inside else 0)
+            if hidden == 64:
+                assert ops.LIVE_STATS["used"] == used[2] + 1
         else:
             assert ops.HIDDEN1_STATS["used"] == used[0] and ops.WGRAD_STATS["used"] == used[1]
         results.append((emb.detach()[named].cpu(), float(loss.detach()), [p.grad.detach().cpu().clone() for p in m.parameters()]))
