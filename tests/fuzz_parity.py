@@ -290,10 +290,11 @@ def one_graph_case(seed):
 
 def one_step_case(seed):
     """Three full steps of the trainer's loop body (trainer.py:213-240: zero_grad, forward, loss, backward,
-    clip_grad_norm_ 1.0, Adam 1e-3) through TrainStep against the oracle's step in float64, dropout off (the
-    masks of TrainStep's own hash stream are covered by the `dropout` mode), features at their natural scale:
-    the loss details and the parameters after every step."""
-    from graphsage_amd import TrainStep
+    clip_grad_norm_ 1.0, Adam 1e-3) through TrainStep against the oracle's step in float64, the dropout masks
+    drawn IN the kernels from TrainStep's (base seed, step, layer) stream and handed to the oracle from the host
+    mirror of that stream, features at their natural scale: loss details and clipped gradients of every step."""
+    from graphsage_amd import TrainStep, rng
+    from graphsage_amd.graphsage import mix_seed
     g = torch.Generator().manual_seed(seed)
     r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
     hidden = (64, 64, 128)[r(0, 2)]
@@ -304,15 +305,17 @@ def one_step_case(seed):
     b, k = r(8, 1500), r(1, 7)
     force = r(0, 1)
     ops.HIDDEN1_MIN_BYTES = 0 if force else (1 << 62)
-    cfg = dict(in_channels=7, hidden_channels=hidden, out_channels=hidden, num_layers=layers, dropout=0.0)
+    p = (0.0, 0.3, 0.3, 0.5)[r(0, 3)]
+    cfg = dict(in_channels=7, hidden_channels=hidden, out_channels=hidden, num_layers=layers, dropout=p)
     torch.manual_seed(seed)
     ref = O.OracleGraphSAGE(**cfg).train()
     m = GraphSAGE(**cfg)
     m.load_state_dict(ref.state_dict(), strict=True)
-    ts = TrainStep(m.cuda(), x.cuda(), ei.cuda())
+    base = (r(0, (1 << 31) - 1) << 31) ^ r(0, (1 << 31) - 1)
+    ts = TrainStep(m.cuda(), x.cuda(), ei.cuda(), seed=base)
     refx = copy.deepcopy(ref).double()
     optx = O.make_adam(refx)
-    tag = f"step seed {seed}: n={n} E={ei.size(1)} hidden={hidden} layers={layers} B={b} K={k} " \
+    tag = f"step seed {seed}: n={n} E={ei.size(1)} hidden={hidden} layers={layers} p={p} B={b} K={k} " \
           f"recompute={'forced' if force else 'off'}"
     # Trajectories of two correct fp32 runs part ways at the first hidden unit that a 1e-7 difference in the
     # parameters carries across the ReLU kink (seed 98: gradients 9e-4 apart at step 2 from parameters 3e-7
@@ -328,7 +331,13 @@ def one_step_case(seed):
         refx.load_state_dict({k_: v.detach().cpu().double() for k_, v in m.state_dict().items()})
         pres = []
         hooks = [cv.register_forward_hook(lambda mod, i, o: pres.append(o.detach())) for cv in refx.convs[:-1]]
-        _, xdet = O.train_step(refx, optx, x.double(), ei, t, c, neg)
+        # the masks the kernels will draw for this step: TrainStep's stream is f(base seed, step, layer),
+        # the hash is mirrored on the host (graphsage_amd/rng.py)
+        keep = None
+        if p > 0.0 and layers > 1:
+            keep = [torch.from_numpy(rng.dropout_keep_mask(mix_seed(base, step, li), n, hidden, p)).double()
+                    for li in range(layers - 1)]
+        _, xdet = O.train_step(refx, optx, x.double(), ei, t, c, neg, keep_masks=keep)
         for h in hooks:
             h.remove()
         kink_cols = [set((pr.abs() < 2e-6 * float(pr.abs().max())).any(0).nonzero().flatten().tolist())

@@ -75,7 +75,8 @@ def test_random_training_steps_against_float64_from_the_same_point():
     judged from where it starts: the float64 oracle is given our parameters, both step; loss details at 1e-5,
     clipped gradients tensor by tensor at 2e-5 (relative Frobenius), a remaining difference only when a
     hidden pre-activation sits on the kink -- then in its column, with the layers behind equal up to the one
-    factor clip_grad_norm_ introduces.  4 000 cases (12 000 steps) ran clean, 22 on a kink."""
+    factor clip_grad_norm_ introduces.  Dropout 0 / 0.3 / 0.5 with the masks drawn in the kernels from TrainStep's
+    (base seed, step, layer) stream and mirrored on the host for the oracle.  8 000 cases (24 000 steps) ran clean."""
     import fuzz_parity
     from graphsage_amd import ops
     keep = ops.HIDDEN1_MIN_BYTES
