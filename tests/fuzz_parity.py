@@ -424,12 +424,56 @@ def one_feeder_case(seed):
     return tag + f"; sampler n={n} E={ei.size(1)} {b} x {k} draws from counter {first}"
 
 
+def one_captured_case(seed):
+    """The whole step as a replayed HIP graph (TrainStep.capture_step: raw device addresses baked into the
+    graph, static batch buffers) against the same steps launched eagerly, dropout off so that both draw no
+    masks: four batches, parameters compared after each -- bitwise where the deterministic loss backward
+    runs in both (nothing in the step uses float atomics then); otherwise Adam spreads the last bits of
+    the gradients over the coordinates and the parameters agree to ~1e-6 (bound asserted: 1e-4)."""
+    from graphsage_amd import TrainStep
+    g = torch.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))       # noqa: E731
+    hidden = (64, 64, 128)[r(0, 2)]
+    layers = (2, 2, 3, 1)[r(0, 3)]
+    n = r(20, 2500) if hidden == 64 else r(20, 700)
+    ei = random_graph(g, n).cuda()
+    x = torch.rand(n, 7, generator=g).cuda()
+    b, k = r(8, 1200), r(1, 7)
+    force = r(0, 1)
+    ops.HIDDEN1_MIN_BYTES = 0 if force else (1 << 62)
+    cfg = dict(in_channels=7, hidden_channels=hidden, out_channels=hidden, num_layers=layers, dropout=0.0)
+    torch.manual_seed(seed)
+    m1 = GraphSAGE(**cfg).cuda()
+    m2 = GraphSAGE(**cfg).cuda()
+    m2.load_state_dict(m1.state_dict())
+    eager, graph = TrainStep(m1, x, ei, seed=1), TrainStep(m2, x, ei, seed=1)
+    graph.capture_step(b, k, preserve_state=True)
+    tag = f"captured seed {seed}: n={n} E={ei.size(1)} hidden={hidden} layers={layers} B={b} K={k} " \
+          f"recompute={'forced' if force else 'off'}"
+    exact, worst = True, 0.0
+    for step in range(4):
+        t = torch.randint(0, n, (b,), generator=g).cuda()
+        c = torch.randint(0, n, (b,), generator=g).cuda()
+        neg = torch.randint(0, n, (b, k), generator=g).cuda()
+        s1 = eager.step(t, c, neg).clone()
+        s2 = graph.step_captured(t, c, neg).clone()
+        assert float((s1[:7] - s2[:7]).abs().max()) <= 1e-6 * float(s1[:7].abs().max()) + 1e-9, (tag, step, "stats")
+        for (name, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            if not torch.equal(p1, p2):
+                exact = False
+                rel = float((p1 - p2).norm() / p1.norm().clamp_min(1e-30))
+                worst = max(worst, rel)
+                assert rel <= 1e-4, (tag, step, name, rel)
+    WORST[0] = max(WORST[0], worst)
+    return tag + ("  (bitwise)" if exact else f"  (parameters within {worst:.1e}, relative Frobenius)")
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     keep_default = (ops.HIDDEN1_MIN_BYTES, ops.BLOCKED_MIN_BYTES)
     mode = sys.argv[3] if len(sys.argv) > 3 else "train"
-    case = {"eval": one_eval_case, "loss": one_loss_case, "dropout": one_dropout_case, "graph": one_graph_case, "step": one_step_case, "feeder": one_feeder_case}.get(mode, one_case)
+    case = {"eval": one_eval_case, "loss": one_loss_case, "dropout": one_dropout_case, "graph": one_graph_case, "step": one_step_case, "feeder": one_feeder_case, "captured": one_captured_case}.get(mode, one_case)
     try:
         for s in range(first, first + cases):
             print(case(s) + ": ok", flush=True)
